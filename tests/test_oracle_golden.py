@@ -1,0 +1,191 @@
+"""Pin the CPU oracle to the golden vectors captured from the real reference (CPU-only)."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ppo_oracle as O
+from tests.util import gae_big_inputs, load
+
+
+def _sha(a):
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)
+
+
+# ------------------------------------------------------------------ GAE (src/ppo.py:125-157)
+def test_gae_oracle_bit_exact_vs_reference():
+    z = load("gae.npz")
+    n_small = n_big = 0
+    for name in z["names"]:
+        T, N, gamma, lam = z[f"{name}/meta"]
+        T, N = int(T), int(N)
+        if f"{name}/seed" in z.files:
+            ci = int(z[f"{name}/seed"][1])
+            r, v, d, nv, nd = gae_big_inputs(ci, T, N)
+            assert (_sha(np.concatenate([r.ravel(), v.ravel(), d.ravel()])) == z[f"{name}/in_sha"]).all()
+            ret, adv = O.gae(r, v, d, nv, nd, gamma, lam, O.GAE_MODE_GAE)
+            assert (_sha(adv) == z[f"{name}/adv_gae_sha"]).all()
+            assert (_sha(ret) == z[f"{name}/ret_gae_sha"]).all()
+            ret, adv = O.gae(r, v, d, nv, nd, gamma, lam, O.GAE_MODE_NORMAL)
+            assert (_sha(adv) == z[f"{name}/adv_norm_sha"]).all()
+            assert (_sha(ret) == z[f"{name}/ret_norm_sha"]).all()
+            n_big += 1
+            continue
+        args = [z[f"{name}/{k}"] for k in ("rewards", "values", "terminals", "next_value", "next_done")]
+        ret, adv = O.gae(*args, gamma, lam, O.GAE_MODE_GAE)
+        np.testing.assert_array_equal(adv, z[f"{name}/adv_gae"])
+        np.testing.assert_array_equal(ret, z[f"{name}/ret_gae"])
+        ret, adv = O.gae(*args, gamma, lam, O.GAE_MODE_NORMAL)
+        np.testing.assert_array_equal(adv, z[f"{name}/adv_norm"])
+        np.testing.assert_array_equal(ret, z[f"{name}/ret_norm"])
+        if f"{name}/adv_skip" in z.files:   # robot_ppo.run_gae, bootstrap branch dead (F4)
+            ret, adv = O.gae(*args, gamma, lam, O.GAE_MODE_SKIP_LAST)
+            np.testing.assert_array_equal(adv, z[f"{name}/adv_skip"])
+            np.testing.assert_array_equal(ret, z[f"{name}/ret_skip"])
+        n_small += 1
+    assert n_small >= 18 and n_big == 2
+
+
+def test_gae_lambda_one_equals_discounted_return_minus_value():
+    # property: lam=1 ties run_gae to normal_advantage
+    rs = np.random.RandomState(3)
+    r, v = rs.standard_normal((32, 9)).astype(np.float32), rs.standard_normal((32, 9)).astype(np.float32)
+    d = (rs.random_sample((32, 9)) < 0.1).astype(np.float32)
+    nv, nd = rs.standard_normal(9).astype(np.float32), np.zeros(9, np.float32)
+    ret_g, adv_g = O.gae(r, v, d, nv, nd, 0.99, 1.0, O.GAE_MODE_GAE)
+    ret_n, adv_n = O.gae(r, v, d, nv, nd, 0.99, 1.0, O.GAE_MODE_NORMAL)
+    np.testing.assert_allclose(adv_g, adv_n, atol=2e-5)
+
+
+def test_skip_last_known_answer():
+    # rewards=1, values=0, T=6 -> adv = [4.439, 3.657, 2.825, 1.9405, 1.0, 0.0]
+    T = 6
+    ret, adv = O.gae(np.ones((T, 1), np.float32), np.zeros((T, 1), np.float32), np.zeros((T, 1), np.float32),
+                     np.zeros(1, np.float32), np.zeros(1, np.float32), 0.99, 0.95, O.GAE_MODE_SKIP_LAST)
+    np.testing.assert_allclose(adv[:, 0], [4.439, 3.657, 2.825, 1.9405, 1.0, 0.0], atol=1e-3)
+
+
+# ------------------------------------------------------------------ shuffle (src/ppo.py:182,213-217)
+def test_mt19937_restatement_matches_numpy_and_golden():
+    z = load("shuffle.npz")
+    for B in (8, 16, 512, 4096):
+        rng = O.MT19937(1)
+        perms = []
+        for upd in range(2):
+            b = np.arange(B)
+            for ep in range(4):
+                rng.shuffle(b)
+                perms.append(b.copy())
+        np.testing.assert_array_equal(np.stack(perms), z[f"B{B}/perms"])
+        key, pos = rng.get_state()
+        np.testing.assert_array_equal(key, z[f"B{B}/state_key"])
+        assert pos == int(z[f"B{B}/state_pos"][0])
+    # survey appendix B known answers
+    b = np.arange(8); O.MT19937(1).shuffle(b)
+    assert b.tolist() == [7, 2, 1, 6, 0, 4, 3, 5]
+    b = np.arange(16); O.MT19937(1).shuffle(b)
+    assert b.tolist() == [3, 13, 7, 2, 6, 10, 4, 1, 14, 0, 15, 9, 8, 12, 11, 5]
+
+
+def test_epoch_permutations_large_match_golden_digests():
+    z = load("shuffle.npz")
+    for B in (65536, 131072, 524288):
+        rs = np.random.RandomState(1)
+        perms = O.epoch_permutations(rs, B, 4) + O.epoch_permutations(rs, B, 4)
+        for k, p in enumerate(perms):
+            assert sorted(p[:64].tolist()) != p[:64].tolist()
+            assert (_sha(p.astype(np.int32)) == z[f"B{B}/sha"][k]).all()
+            np.testing.assert_array_equal(p[:16], z[f"B{B}/head"][k])
+    assert perms[0][:6].tolist() == [398286, 75382, 38857, 439132, 433034, 139948]
+
+
+# ------------------------------------------------------------------ loss (src/ppo.py:225-264)
+def test_loss_oracle_vs_reference_autograd():
+    z = load("loss.npz")
+    for name in z["names"]:
+        T, N, norm_adv, clip_vloss, clip, ec, vc = z[f"{name}/meta"]
+        a = {k: z[f"{name}/{k}"] for k in ("newlogp", "oldlogp", "adv", "newv", "oldv", "ret", "entropy")}
+        # the advantages the reference fed its loss come from its own run_gae: tie that in too
+        ret, adv = O.gae(z[f"{name}/rewards"], a["oldv"].reshape(int(T), int(N)), z[f"{name}/terminals"],
+                         z[f"{name}/next_value"], z[f"{name}/next_done"], 0.99, 0.95)
+        np.testing.assert_array_equal(adv.reshape(-1), a["adv"])
+        np.testing.assert_array_equal(ret.reshape(-1), a["ret"])
+        mode = O.VLOSS_CLIPPED if clip_vloss else O.VLOSS_OLDVALUES   # ppo.py:261 quirk (F8)
+        sc, g_lp, g_v, g_e = O.ppo_loss(a["newlogp"], a["oldlogp"], a["adv"], a["newv"], a["oldv"], a["ret"],
+                                        a["entropy"], clip, ec, vc, bool(norm_adv), mode)
+        ref = z[f"{name}/scalars"]   # policy_loss, value_loss, entropy, old_kl, kl, clipfrac
+        if int(T) * int(N) == 2 and norm_adv:
+            continue  # M=2: std of two points; covered below with looser tolerance
+        np.testing.assert_allclose(sc[[1, 2, 3, 4, 5, 6]], ref, rtol=2e-6, atol=2e-7, err_msg=name)
+        np.testing.assert_allclose(g_lp, z[f"{name}/g_newlogp"], rtol=1e-5, atol=1e-9, err_msg=name)
+        np.testing.assert_allclose(g_v, z[f"{name}/g_newv"], rtol=1e-5, atol=1e-9, err_msg=name)
+        np.testing.assert_allclose(g_e, z[f"{name}/g_entropy"], rtol=1e-6, atol=0, err_msg=name)
+
+
+def test_loss_oracle_tiny_minibatch():
+    z = load("loss.npz")
+    name = [n for n in z["names"] if "T1_N2" in n][0]
+    a = {k: z[f"{name}/{k}"] for k in ("newlogp", "oldlogp", "adv", "newv", "oldv", "ret", "entropy")}
+    sc, g_lp, g_v, g_e = O.ppo_loss(a["newlogp"], a["oldlogp"], a["adv"], a["newv"], a["oldv"], a["ret"],
+                                    a["entropy"], 0.2, 0.01, 0.5, True, O.VLOSS_CLIPPED)
+    np.testing.assert_allclose(sc[[1, 2, 3, 4, 5, 6]], z[f"{name}/scalars"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(g_lp, z[f"{name}/g_newlogp"], rtol=1e-5, atol=1e-8)
+
+
+# ------------------------------------------------------------------ model (src/models/actor_critic.py:34-51)
+def test_oracle_actor_critic_matches_reference_evaluate_and_init():
+    z = load("evaluate.npz")
+    for name in z["names"]:
+        D, A, cont, layers, hid = (int(x) for x in z[f"{name}/meta"])
+        torch.manual_seed(1)
+        net = O.make_actor_critic(D, (A,) if cont else A, hid, layers, bool(cont))
+        for k, v in net.state_dict().items():       # same RNG draws as the reference's construction order
+            # (orthogonal_ runs LAPACK QR, whose last bits depend on the thread count -> tolerance)
+            np.testing.assert_allclose(v.numpy(), z[f"{name}/init/{k}"], rtol=0, atol=2e-6, err_msg=f"{name} {k}")
+        net.load_state_dict({k: torch.from_numpy(z[f"{name}/sd/{k}"]) for k in net.state_dict()})
+        obs, act = torch.from_numpy(z[f"{name}/obs"]), torch.from_numpy(z[f"{name}/act"])
+        _, logp, ent, val = net.evaluate(obs, act)
+        np.testing.assert_allclose(logp.detach().numpy(), z[f"{name}/logp"], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(ent.detach().numpy(), z[f"{name}/ent"], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(val.detach().numpy(), z[f"{name}/val"], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(net.value(obs).detach().numpy(), z[f"{name}/value_fn"], rtol=1e-6, atol=1e-6)
+
+
+# ------------------------------------------------------------------ whole update (src/ppo.py:192-292)
+@pytest.mark.parametrize("name", ["cfg1_discrete", "cfg2_continuous", "cfg3_normal_adv_tail"])
+def test_reference_update_restatement_reproduces_reference_train_trace(name):
+    torch.set_num_threads(1)
+    z = load("trace.npz")
+    hp = dict(eval(str(z[f"{name}/params"])))
+    init = {k[len(name) + 6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(f"{name}/init/")}
+    D = init["actor.net.0.weight"].shape[1]
+    A = init["actor.net.4.weight"].shape[0]
+    cont = bool(hp["continuous"])
+    net = O.make_actor_critic(D, (A,) if cont else A, hp["hidden_dim"], hp["num_layers"], cont)
+    net.load_state_dict(init)
+    opt = torch.optim.Adam(net.parameters(), lr=hp["learning_rate"], eps=1e-5)
+    rng = np.random.RandomState(1)
+    U = int(z[f"{name}/num_updates"][0])
+    B = hp["num_envs"] * hp["num_steps"]
+    assert U == hp["total_timesteps"] // B
+    perms_all = []
+    ref_sc = z[f"{name}/scalars"]
+    for u in range(U):
+        frac = 1.0 - u / U
+        opt.param_groups[0]["lr"] = frac * hp["learning_rate"]          # src/ppo.py:195-198
+        assert abs(opt.param_groups[0]["lr"] - float(z[f"{name}/u{u}/lr"][0])) < 1e-12
+        buf = {k: torch.from_numpy(z[f"{name}/u{u}/{k}"]) for k in
+               ("states", "actions", "log_probs", "rewards", "terminals", "values")}
+        res = O.reference_update(net, opt, buf, torch.from_numpy(z[f"{name}/u{u}/next_obs"]),
+                                 torch.from_numpy(z[f"{name}/u{u}/next_done"]), hp, rng)
+        np.testing.assert_array_equal(res["advantages"].numpy(), z[f"{name}/u{u}/advantages"])
+        np.testing.assert_array_equal(res["returns"].numpy(), z[f"{name}/u{u}/returns"])
+        perms_all += res["perms"]
+        last = res["scalars"][-1]   # logged values are the LAST minibatch's (src/ppo.py:284-288)
+        # tags: lr, value_loss, policy_loss, entropy, old_kl, kl, clipfrac(mean over update), explained_var
+        np.testing.assert_allclose([last[2], last[1], last[3], last[4], last[5]], ref_sc[u][1:6], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(res["scalars"][:, 6].mean(), ref_sc[u][6], rtol=1e-6, atol=1e-9)
+    np.testing.assert_array_equal(np.stack(perms_all), z[f"{name}/perms"])
+    for k, v in net.state_dict().items():
+        np.testing.assert_allclose(v.numpy(), z[f"{name}/final/{k}"], rtol=1e-5, atol=1e-7, err_msg=k)
