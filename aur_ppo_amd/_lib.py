@@ -1,0 +1,61 @@
+"""ctypes binding of libaurppo_hip.so (declarations mirror include/aurppo.h one to one)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libaurppo_hip.so")
+
+# every symbol include/aurppo.h declares (tests/test_abi.py checks the header against this list)
+SYMBOLS = (
+    "aurppo_version", "aurppo_last_error", "aurppo_device_count", "aurppo_gae_f32",
+    "aurppo_mt19937_create", "aurppo_mt19937_destroy", "aurppo_mt19937_seed", "aurppo_mt19937_get_state",
+    "aurppo_mt19937_set_state", "aurppo_arange_i32", "aurppo_shuffle_i32", "aurppo_shuffle_epochs_i32",
+    "aurppo_gather_f32", "aurppo_loss_workspace_bytes", "aurppo_loss_fwd_bwd_f32",
+    "aurppo_clip_workspace_bytes", "aurppo_grad_norm_clip_f32",
+)
+
+_lib = None
+
+
+class AurppoLibraryMissing(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load the HIP library or fail loudly -- there is no fallback implementation."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AurppoLibraryMissing(
+            f"{LIB_PATH} not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). aur_ppo_amd has no CPU or PyTorch fallback for its kernels.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, f64 = C.c_void_p, C.c_int, C.c_double
+    lib.aurppo_version.restype = i32
+    lib.aurppo_last_error.restype = C.c_char_p
+    lib.aurppo_device_count.restype = i32
+    lib.aurppo_gae_f32.argtypes = [vp] * 7 + [i32, i32, f64, f64, i32, vp]
+    lib.aurppo_mt19937_create.argtypes = [C.POINTER(vp), C.c_uint32, i32, vp]
+    lib.aurppo_mt19937_destroy.argtypes = [vp]
+    lib.aurppo_mt19937_seed.argtypes = [vp, C.c_uint32, vp]
+    lib.aurppo_mt19937_get_state.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_int32), vp]
+    lib.aurppo_mt19937_set_state.argtypes = [vp, C.POINTER(C.c_uint32), C.c_int32, vp]
+    lib.aurppo_arange_i32.argtypes = [vp, i32, vp]
+    lib.aurppo_shuffle_i32.argtypes = [vp, vp, i32, vp]
+    lib.aurppo_shuffle_epochs_i32.argtypes = [vp, vp, i32, i32, vp]
+    lib.aurppo_gather_f32.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(i32), i32, vp]
+    lib.aurppo_loss_workspace_bytes.argtypes = [i32]
+    lib.aurppo_loss_workspace_bytes.restype = C.c_size_t
+    lib.aurppo_loss_fwd_bwd_f32.argtypes = [vp] * 7 + [i32, f64, f64, f64, i32, i32] + [vp] * 6
+    lib.aurppo_clip_workspace_bytes.argtypes = [C.c_int64]
+    lib.aurppo_clip_workspace_bytes.restype = C.c_size_t
+    lib.aurppo_grad_norm_clip_f32.argtypes = [vp, C.c_int64, f64, vp, vp, vp]
+    for name in SYMBOLS:
+        fn = getattr(lib, name)
+        if name not in ("aurppo_last_error", "aurppo_loss_workspace_bytes", "aurppo_clip_workspace_bytes"):
+            fn.restype = i32
+    _lib = lib
+    return lib

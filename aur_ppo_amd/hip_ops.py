@@ -1,0 +1,214 @@
+"""Torch-facing wrappers over the C ABI (include/aurppo.h).  Tensors must be CUDA(HIP), fp32 /
+int32, contiguous; every call enqueues on torch's CURRENT stream and returns without syncing."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+GAE, NORMAL_ADV, GAE_SKIP_LAST = 0, 1, 2
+VLOSS_RETURNS, VLOSS_CLIPPED, VLOSS_OLDVALUES = 0, 1, 2
+S_LOSS, S_PG, S_VL, S_ENT, S_OLD_KL, S_KL, S_CLIPFRAC, S_ADV_MEAN, S_ADV_STD = range(9)
+N_SCALARS = 9
+
+
+def _lib_or_raise():
+    lib = _lib.load()
+    if not torch.cuda.is_available():
+        raise RuntimeError("aur_ppo_amd.hip_ops needs a gfx950 GPU: the HIP kernels have no CPU fallback")
+    return lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (rc={rc}): {_lib.load().aurppo_last_error().decode()}")
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t, dtype=torch.float32):
+    if not (t.is_cuda and t.dtype == dtype and t.is_contiguous()):
+        raise ValueError(f"expected a contiguous CUDA {dtype} tensor, got {t.dtype} on {t.device}, "
+                         f"contiguous={t.is_contiguous()}")
+    return C.c_void_p(t.data_ptr())
+
+
+_ws_cache = {}
+
+
+def _workspace(kind, nbytes, device):
+    key = (kind, device.index if device.index is not None else torch.cuda.current_device())
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+# ------------------------------------------------------------------ K1
+def gae(rewards, values, terminals, next_value, next_done, gamma, lam, mode=GAE, out=None):
+    """``ppo.run_gae`` / ``normal_advantage`` (src/ppo.py:125-157).  Returns (returns, advantages)."""
+    lib = _lib_or_raise()
+    T, N = rewards.shape
+    if values.shape != (T, N) or terminals.shape != (T, N) or next_value.numel() != N or next_done.numel() != N:
+        raise ValueError(f"shape mismatch: rewards {tuple(rewards.shape)}, values {tuple(values.shape)}, terminals "
+                         f"{tuple(terminals.shape)}, next_value {tuple(next_value.shape)}, next_done {tuple(next_done.shape)}")
+    if out is None:
+        adv, ret = torch.empty_like(rewards), torch.empty_like(rewards)
+    else:
+        ret, adv = out
+    _check(lib.aurppo_gae_f32(_ptr(rewards), _ptr(values), _ptr(terminals), _ptr(next_value), _ptr(next_done),
+                              _ptr(adv), _ptr(ret), T, N, float(gamma), float(lam), int(mode), _stream()),
+           "aurppo_gae_f32")
+    return ret, adv
+
+
+# ------------------------------------------------------------------ K2
+class MT19937:
+    """Device-resident twin of numpy's global legacy stream: ``np.random.seed`` (src/ppo.py:182) and
+    ``np.random.shuffle`` (src/ppo.py:217)."""
+
+    def __init__(self, seed: int, max_n: int, device=None):
+        lib = _lib_or_raise()
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.max_n = int(max_n)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _check(lib.aurppo_mt19937_create(C.byref(h), int(seed) & 0xFFFFFFFF, self.max_n, _stream()),
+                   "aurppo_mt19937_create")
+        self._h = h
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                _lib.load().aurppo_mt19937_destroy(h)
+            except Exception:
+                pass
+
+    def seed(self, seed: int):
+        _check(_lib.load().aurppo_mt19937_seed(self._h, int(seed) & 0xFFFFFFFF, _stream()), "aurppo_mt19937_seed")
+
+    def get_state(self):
+        key = np.empty(624, np.uint32)
+        pos = C.c_int32()
+        _check(_lib.load().aurppo_mt19937_get_state(self._h, key.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(pos),
+                                                    _stream()), "aurppo_mt19937_get_state")
+        return key, int(pos.value)
+
+    def set_state(self, key, pos):
+        key = np.ascontiguousarray(key, dtype=np.uint32)
+        assert key.shape == (624,)
+        _check(_lib.load().aurppo_mt19937_set_state(self._h, key.ctypes.data_as(C.POINTER(C.c_uint32)), int(pos),
+                                                    _stream()), "aurppo_mt19937_set_state")
+
+    def shuffle_(self, idx):
+        """In-place ``np.random.shuffle`` of an int32 device vector."""
+        _check(_lib.load().aurppo_shuffle_i32(self._h, _ptr(idx, torch.int32), idx.numel(), _stream()),
+               "aurppo_shuffle_i32")
+        return idx
+
+    def shuffle_epochs(self, n: int, epochs: int, out=None):
+        """The ``epochs`` index arrays of one update (arange once, shuffled in place per epoch,
+        src/ppo.py:213-217) as an (epochs, n) int32 tensor."""
+        if out is None:
+            out = torch.empty((epochs, n), dtype=torch.int32, device=self.device)
+        _check(_lib.load().aurppo_shuffle_epochs_i32(self._h, _ptr(out, torch.int32), int(n), int(epochs), _stream()),
+               "aurppo_shuffle_epochs_i32")
+        return out
+
+
+def arange_i32(n, device):
+    out = torch.empty(n, dtype=torch.int32, device=device)
+    _check(_lib_or_raise().aurppo_arange_i32(_ptr(out, torch.int32), n, _stream()), "aurppo_arange_i32")
+    return out
+
+
+# ------------------------------------------------------------------ K3
+def gather(idx, srcs, outs=None):
+    """One fused launch for ``[s[idx] for s in srcs]`` (src/ppo.py:219-220,225,236,251-257).
+    ``srcs``: flattened buffer tensors (B, ...) sharing dim 0; ``idx``: int32 (M,)."""
+    lib = _lib_or_raise()
+    M = idx.numel()
+    n = len(srcs)
+    if outs is None:
+        outs = [torch.empty((M,) + tuple(s.shape[1:]), dtype=torch.float32, device=s.device) for s in srcs]
+    row = [int(np.prod(s.shape[1:])) if s.dim() > 1 else 1 for s in srcs]
+    for s, o, r in zip(srcs, outs, row):
+        if o.numel() != M * r:
+            raise ValueError(f"gather: destination has {o.numel()} elements, expected {M}*{r}")
+    VP = C.c_void_p * n
+    src_a = VP(*[s.data_ptr() for s in srcs])
+    dst_a = VP(*[o.data_ptr() for o in outs])
+    for t in list(srcs) + list(outs):
+        _ptr(t)
+    row_a = (C.c_int * n)(*row)
+    _check(lib.aurppo_gather_f32(_ptr(idx, torch.int32), M, src_a, dst_a, row_a, n, _stream()), "aurppo_gather_f32")
+    return outs
+
+
+# ------------------------------------------------------------------ K4 + K5
+def loss_fwd_bwd(newlogp, oldlogp, adv, newv, oldv, ret, entropy, clip, ent_coef, vf_coef, norm_adv=True,
+                 vloss_mode=VLOSS_CLIPPED, out_scalars=None):
+    """src/ppo.py:225-264 forward and backward.  Returns (scalars[9], g_newlogp, g_newv, g_entropy)."""
+    lib = _lib_or_raise()
+    M = newlogp.numel()
+    for t in (oldlogp, adv, newv, oldv, ret, entropy):
+        if t.numel() != M:
+            raise ValueError(f"loss_fwd_bwd: expected {M} elements, got {t.numel()}")
+    dev = newlogp.device
+    if out_scalars is None:
+        out_scalars = torch.empty(N_SCALARS, dtype=torch.float32, device=dev)
+    g_lp, g_v, g_e = (torch.empty(M, dtype=torch.float32, device=dev) for _ in range(3))
+    ws = _workspace("loss", lib.aurppo_loss_workspace_bytes(M), dev)
+    _check(lib.aurppo_loss_fwd_bwd_f32(_ptr(newlogp), _ptr(oldlogp), _ptr(adv), _ptr(newv), _ptr(oldv), _ptr(ret),
+                                       _ptr(entropy), M, float(clip), float(ent_coef), float(vf_coef),
+                                       int(bool(norm_adv)), int(vloss_mode), _ptr(out_scalars), _ptr(g_lp), _ptr(g_v),
+                                       _ptr(g_e), C.c_void_p(ws.data_ptr()), _stream()), "aurppo_loss_fwd_bwd_f32")
+    return out_scalars, g_lp, g_v, g_e
+
+
+class PPOLossFn(torch.autograd.Function):
+    """``loss = ppo_loss(newlogp, newvalue, entropy, ...)`` with the reference's semantics; the
+    HIP kernel produces the three input gradients in the forward pass, backward only scales them."""
+
+    @staticmethod
+    def forward(ctx, newlogp, newv, entropy, oldlogp, adv, oldv, ret, clip, ent_coef, vf_coef, norm_adv, vloss_mode,
+                out_scalars):
+        nv = newv.reshape(-1)
+        sc, g_lp, g_v, g_e = loss_fwd_bwd(newlogp.detach().contiguous(), oldlogp, adv, nv.detach().contiguous(), oldv,
+                                          ret, entropy.detach().contiguous(), clip, ent_coef, vf_coef, norm_adv,
+                                          vloss_mode, out_scalars)
+        ctx.save_for_backward(g_lp, g_v, g_e)
+        ctx.v_shape = newv.shape
+        return sc[S_LOSS].clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        g_lp, g_v, g_e = ctx.saved_tensors
+        return (g_lp * grad_out, (g_v * grad_out).view(ctx.v_shape), g_e * grad_out) + (None,) * 10
+
+
+def ppo_loss(newlogp, newv, entropy, oldlogp, adv, oldv, ret, clip, ent_coef, vf_coef, norm_adv=True,
+             vloss_mode=VLOSS_CLIPPED, out_scalars=None):
+    return PPOLossFn.apply(newlogp, newv, entropy, oldlogp, adv, oldv, ret, clip, ent_coef, vf_coef, norm_adv,
+                           vloss_mode, out_scalars)
+
+
+# ------------------------------------------------------------------ K6
+def grad_norm_clip_(flat_grads, max_norm, out_norm=None):
+    """In-place ``clip_grad_norm_`` over one flat gradient bucket (src/ppo.py:268).  Returns the
+    pre-clip norm as a 1-element device tensor."""
+    lib = _lib_or_raise()
+    n = flat_grads.numel()
+    if out_norm is None:
+        out_norm = torch.empty(1, dtype=torch.float32, device=flat_grads.device)
+    ws = _workspace("clip", lib.aurppo_clip_workspace_bytes(n), flat_grads.device)
+    _check(lib.aurppo_grad_norm_clip_f32(_ptr(flat_grads), n, float(max_norm), _ptr(out_norm),
+                                         C.c_void_p(ws.data_ptr()), _stream()), "aurppo_grad_norm_clip_f32")
+    return out_norm

@@ -1,0 +1,137 @@
+/*
+ * aurppo.h -- C ABI of libaurppo_hip.so: the MI355X (gfx950) hot path of the aur_ppo trainer.
+ *
+ * The reference (biirving/aur_ppo) is pure Python/PyTorch and has no FFI of its own; the seam this
+ * library replaces is the block of torch-op chains between "rollout buffer filled" and
+ * "loss.backward()" in src/ppo.py / src/robot_ppo.py.  Each entry point cites the reference lines
+ * whose arithmetic it performs.  Binding stub a maintainer would add: INTEGRATION.md (ctypes).
+ *
+ * Conventions
+ *   - Every pointer is a DEVICE pointer unless its name ends in _h.  Tensors are fp32, contiguous.
+ *     Rollout tensors are time-major (T, N): element (t, n) at t*N + n -- the layout of
+ *     torch_buffer (src/ppo.py:24-29) and of buffer.flatten() (src/ppo.py:32-39).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls enqueue and
+ *     return; they never allocate, never synchronise (except the *_get_state/_set_state helpers).
+ *     All entry points are safe to capture into a hipGraph.
+ *   - Return 0 on success, <0 on error; aurppo_last_error() gives a thread-local message.
+ *   - The caller owns all tensors.  The library owns only RNG handles.
+ *   - No CPU fallbacks exist in this library: without a gfx950 device every compute call fails.
+ */
+#ifndef AURPPO_H
+#define AURPPO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AURPPO_OK 0
+#define AURPPO_EINVAL (-1) /* null pointer, bad enum, misaligned workspace            */
+#define AURPPO_ESHAPE (-2) /* non-positive / inconsistent sizes, workspace too small  */
+#define AURPPO_EHIP (-3)   /* a HIP runtime call failed (launch error, no device ...) */
+
+#define AURPPO_VERSION 1
+
+/* gae `mode` */
+#define AURPPO_GAE 0           /* ppo.run_gae                       src/ppo.py:125-142        */
+#define AURPPO_NORMAL_ADV 1    /* ppo.normal_advantage              src/ppo.py:145-157        */
+#define AURPPO_GAE_SKIP_LAST 2 /* robot_ppo.run_gae as written      src/robot_ppo.py:224-244  */
+
+/* loss `vloss_mode` (a bool clip_vloss maps to 1; the two un-clipped flavours differ upstream) */
+#define AURPPO_VLOSS_RETURNS 0   /* 0.5*mean((v-R)^2)               src/robot_ppo.py:390      */
+#define AURPPO_VLOSS_CLIPPED 1   /* clipped value loss              src/ppo.py:250-259        */
+#define AURPPO_VLOSS_OLDVALUES 2 /* 0.5*mean((v-V_old)^2)           src/ppo.py:261            */
+
+/* layout of out_scalars written by aurppo_loss_fwd_bwd_f32 */
+#define AURPPO_S_LOSS 0     /* pg - ent_coef*ent + vl*vf_coef       src/ppo.py:264 */
+#define AURPPO_S_PG 1       /* policy_loss                          src/ppo.py:245 */
+#define AURPPO_S_VL 2       /* value_loss (un-weighted)             src/ppo.py:259,261 */
+#define AURPPO_S_ENT 3      /* entropy_loss = mean(entropy)         src/ppo.py:263 */
+#define AURPPO_S_OLD_KL 4   /* mean(-log_ratio)                     src/ppo.py:232 */
+#define AURPPO_S_KL 5       /* mean((ratio-1)-log_ratio)            src/ppo.py:233 */
+#define AURPPO_S_CLIPFRAC 6 /* mean(|ratio-1| > clip)               src/ppo.py:234 */
+#define AURPPO_S_ADV_MEAN 7 /* minibatch advantage mean             src/ppo.py:239 */
+#define AURPPO_S_ADV_STD 8  /* minibatch advantage std (ddof=1)     src/ppo.py:239 */
+#define AURPPO_N_SCALARS 9
+
+#define AURPPO_MAX_STREAMS 8
+
+int aurppo_version(void);
+const char* aurppo_last_error(void);
+/* Number of gfx950 devices visible; <0 on HIP error.  Does not create a context on any of them. */
+int aurppo_device_count(void);
+
+/* ---- K1: advantage estimation -------------------------------------------------------------
+ * Replaces ppo.run_gae / ppo.normal_advantage (src/ppo.py:125-157; duplicates in
+ * src/utils/advantages.py:4-37) and robot_ppo.run_gae (src/robot_ppo.py:224-244, mode 2).
+ *   for t = T-1..0:  nnt = 1 - done[t+1] (next_done at T-1);  nv = V[t+1] (next_value at T-1)
+ *     delta = (r[t] + ((g*nv)*nnt)) - V[t];  A[t] = delta + (((g*lam)*nnt) * A[t+1]);  R = A + V
+ * fp32 with exactly that association and no fused multiply-add (bit-identical to the reference's
+ * CPU result); gamma is rounded to fp32, gamma*lam is formed in fp64 then rounded, as Python does.
+ * Mode 1:  R[t] = r[t] + ((g*nnt)*R[t+1]) (R[T] = next_value);  A = R - V.
+ * Mode 2:  the loop starts at T-2, so A[T-1] = 0 and R[T-1] = V[T-1] (upstream behaviour).       */
+int aurppo_gae_f32(const float* rewards, const float* values, const float* terminals, /* (T,N) */
+                   const float* next_value, const float* next_done,                    /* (N,)  */
+                   float* advantages, float* returns,                                  /* (T,N) out */
+                   int T, int N, double gamma, double lam, int mode, void* stream);
+
+/* ---- K2: numpy-legacy MT19937 + Fisher-Yates shuffle --------------------------------------
+ * Replaces np.random.seed(seed) (src/ppo.py:182) and np.random.shuffle(b_inds) (src/ppo.py:217,
+ * src/robot_ppo.py:338).  Bit-exact with numpy's RandomState: init_genrand seeding, one 32-bit
+ * draw per masked-rejection trial, descending Fisher-Yates.  The handle is a device-resident
+ * generator state; successive shuffles continue the same stream, as the global numpy stream does. */
+typedef struct aurppo_rng aurppo_rng;
+int aurppo_mt19937_create(aurppo_rng** out, uint32_t seed, int max_n, void* stream);
+int aurppo_mt19937_destroy(aurppo_rng* rng);
+int aurppo_mt19937_seed(aurppo_rng* rng, uint32_t seed, void* stream);
+/* Host copies of (key[624], pos) == np.random.get_state()[1:3].  These two synchronise `stream`. */
+int aurppo_mt19937_get_state(aurppo_rng* rng, uint32_t* key_h, int32_t* pos_h, void* stream);
+int aurppo_mt19937_set_state(aurppo_rng* rng, const uint32_t* key_h, int32_t pos_h, void* stream);
+/* idx[i] = i  (np.arange, src/ppo.py:213) */
+int aurppo_arange_i32(int32_t* idx, int n, void* stream);
+/* In-place shuffle of idx[0..n), n <= max_n given at create. */
+int aurppo_shuffle_i32(aurppo_rng* rng, int32_t* idx, int n, void* stream);
+/* `epochs` successive shuffles of one carried array, epoch e written to out[e*n .. (e+1)*n):
+ * out[0] = shuffle(arange(n)), out[e] = shuffle(out[e-1])  (src/ppo.py:213-217).               */
+int aurppo_shuffle_epochs_i32(aurppo_rng* rng, int32_t* out, int n, int epochs, void* stream);
+
+/* ---- K3: fused minibatch gather -----------------------------------------------------------
+ * Replaces the advanced-indexing gathers b_obs[mb_inds], b_actions[mb_inds], b_logprobs[mb_inds],
+ * b_advantages[mb_inds], b_returns[mb_inds], b_values[mb_inds] (src/ppo.py:219-220,225,236,251-257;
+ * src/robot_ppo.py:341-345) with ONE launch over up to 8 streams:
+ *   dst_h[s][m*row_elems_h[s] + e] = src_h[s][idx[m]*row_elems_h[s] + e],  0<=m<M.
+ * src_h/dst_h/row_elems_h are HOST arrays (of device pointers / ints) of length n_streams.       */
+int aurppo_gather_f32(const int32_t* idx, int M, const float* const* src_h, float* const* dst_h,
+                      const int* row_elems_h, int n_streams, void* stream);
+
+/* ---- K4+K5: advantage normalisation + clipped-surrogate loss, forward and backward ---------
+ * Replaces src/ppo.py:225-264 (src/robot_ppo.py:345-398): log-ratio, ratio, KL diagnostics,
+ * clip fraction, minibatch advantage normalisation (mean, unbiased std, +1e-8), policy loss,
+ * value loss (vloss_mode), entropy bonus, total loss -- and their autograd:
+ *   g_newlogp[m] = d loss / d newlogp[m],  g_newv[m] = d loss / d newv[m],
+ *   g_entropy[m] = -ent_coef / M     (torch conventions for max ties and clamp edges).
+ * clip / ent_coef / vf_coef are the Python floats of the params dict (fp64); the clip bounds are
+ * formed as 1-clip, 1+clip in fp64 and rounded to fp32, as torch does.
+ * out_scalars: AURPPO_N_SCALARS floats (device).  workspace: aurppo_loss_workspace_bytes(M)
+ * bytes, 16-byte aligned, contents need not be initialised.                                      */
+size_t aurppo_loss_workspace_bytes(int M);
+int aurppo_loss_fwd_bwd_f32(const float* newlogp, const float* oldlogp, const float* adv,
+                            const float* newv, const float* oldv, const float* ret,
+                            const float* entropy, int M, double clip, double ent_coef, double vf_coef,
+                            int norm_adv, int vloss_mode, float* out_scalars, float* g_newlogp,
+                            float* g_newv, float* g_entropy, void* workspace, void* stream);
+
+/* ---- K6: global-norm gradient clip over one flat bucket -------------------------------------
+ * Replaces nn.utils.clip_grad_norm_(params, max_norm) (src/ppo.py:268; src/robot_ppo.py:401):
+ * norm = ||g||_2, g *= min(1, max_norm / (norm + 1e-6)).  out_norm: 1 float (device), the
+ * pre-clip norm.  workspace: aurppo_clip_workspace_bytes(n) bytes.                               */
+size_t aurppo_clip_workspace_bytes(int64_t n);
+int aurppo_grad_norm_clip_f32(float* flat_grads, int64_t n, double max_norm, float* out_norm,
+                              void* workspace, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AURPPO_H */

@@ -189,3 +189,45 @@ def test_reference_update_restatement_reproduces_reference_train_trace(name):
     np.testing.assert_array_equal(np.stack(perms_all), z[f"{name}/perms"])
     for k, v in net.state_dict().items():
         np.testing.assert_allclose(v.numpy(), z[f"{name}/final/{k}"], rtol=1e-5, atol=1e-7, err_msg=k)
+
+
+# ------------------------------------------------------------------ the C restatement agrees with all of the above
+def test_c_oracle_matches_golden_and_numpy_oracle():
+    from oracle import c_oracle as CO
+    z = load("gae.npz")
+    for name in z["names"]:
+        if f"{name}/seed" in z.files:
+            continue
+        T, N, gamma, lam = z[f"{name}/meta"]
+        args = [z[f"{name}/{k}"] for k in ("rewards", "values", "terminals", "next_value", "next_done")]
+        for mode, key in ((0, "gae"), (1, "norm"), (2, "skip")):
+            if f"{name}/adv_{key}" not in z.files:
+                continue
+            ret, adv = CO.gae(*args, gamma, lam, mode)
+            np.testing.assert_array_equal(adv, z[f"{name}/adv_{key}"])
+            np.testing.assert_array_equal(ret, z[f"{name}/ret_{key}"])
+    zs = load("shuffle.npz")
+    for B in (8, 512, 4096, 65536, 524288):
+        mt = CO.MT(1)
+        for k in range(8):
+            if k % 4 == 0:
+                b = np.arange(B, dtype=np.int32)
+            mt.shuffle(b)
+            if B <= 4096:
+                np.testing.assert_array_equal(b, zs[f"B{B}/perms"][k])
+            else:
+                assert (_sha(b) == zs[f"B{B}/sha"][k]).all()
+        key, pos = mt.get_state()
+        np.testing.assert_array_equal(key, zs[f"B{B}/state_key"])
+        assert pos == int(zs[f"B{B}/state_pos"][0])
+    zl = load("loss.npz")
+    for name in zl["names"]:
+        T, N, norm_adv, clip_vloss, clip, ec, vc = zl[f"{name}/meta"]
+        a = [zl[f"{name}/{k}"] for k in ("newlogp", "oldlogp", "adv", "newv", "oldv", "ret", "entropy")]
+        mode = O.VLOSS_CLIPPED if clip_vloss else O.VLOSS_OLDVALUES
+        sc, g0, g1, g2 = CO.ppo_loss(*a, clip, ec, vc, bool(norm_adv), mode)
+        tol = dict(rtol=1e-5, atol=1e-6) if int(T) * int(N) == 2 else dict(rtol=2e-6, atol=2e-7)
+        np.testing.assert_allclose(sc[[1, 2, 3, 4, 5, 6]], zl[f"{name}/scalars"], err_msg=name, **tol)
+        np.testing.assert_allclose(g0, zl[f"{name}/g_newlogp"], rtol=1e-5, atol=1e-8, err_msg=name)
+        np.testing.assert_allclose(g1, zl[f"{name}/g_newv"], rtol=1e-5, atol=1e-9, err_msg=name)
+        np.testing.assert_allclose(g2, zl[f"{name}/g_entropy"], rtol=1e-6, err_msg=name)
