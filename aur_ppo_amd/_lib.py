@@ -32,6 +32,10 @@ def load() -> C.CDLL:
         raise AurppoLibraryMissing(
             f"{LIB_PATH} not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). aur_ppo_amd has no CPU or PyTorch fallback for its kernels.")
+    # torch ships its own libamdhip64 (same SONAME as /opt/rocm's).  Import torch FIRST so this
+    # library binds to the runtime torch uses: streams and device pointers are only meaningful
+    # inside one HIP runtime instance.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     vp, i32, f64 = C.c_void_p, C.c_int, C.c_double
     lib.aurppo_version.restype = i32

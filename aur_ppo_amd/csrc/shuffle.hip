@@ -280,7 +280,9 @@ extern "C" int aurppo_arange_i32(int32_t* idx, int n, void* stream) {
 }
 
 extern "C" int aurppo_shuffle_i32(aurppo_rng* rng, int32_t* idx, int n, void* stream) {
-    AURPPO_REQUIRE(rng && idx, AURPPO_EINVAL, "aurppo_shuffle_i32: null pointer");
+    AURPPO_REQUIRE(rng, AURPPO_EINVAL, "aurppo_shuffle_i32: null handle");
+    if (n == 0) return AURPPO_OK;
+    AURPPO_REQUIRE(idx, AURPPO_EINVAL, "aurppo_shuffle_i32: null pointer");
     AURPPO_REQUIRE(n >= 0 && n <= rng->max_n, AURPPO_ESHAPE, "aurppo_shuffle_i32: n=%d outside [0, max_n=%d]", n,
                    rng->max_n);
     if (n <= 1) return AURPPO_OK;  // numpy draws nothing for n <= 1

@@ -1,0 +1,68 @@
+"""Env-sharded data parallelism: one process per GPU, ``torch.distributed`` backend "nccl"
+(= RCCL over xGMI).  New relative to the reference, which is single-process; semantics are
+SURVEY section 8e:
+
+* rank r owns envs ``[r*N/W, (r+1)*N/W)`` -- GAE, shuffle, gather, adv-norm and loss are local;
+* exactly one exchange per optimizer step: SUM all-reduce of the flat gradient bucket, divided
+  by W, then the identical clip + Adam on every rank (norm taken on the reduced gradient);
+* with ``target_kl`` set, one extra 1-float all-reduce (mean) per epoch so ranks stop together.
+
+xGMI is point-to-point (7 links/GPU): the 68 KB MLP bucket is latency-bound, so it goes out as a
+single message; nothing here is bucketed or ring-tuned.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def init_from_env(backend=None):
+    """Initialise the default process group from torchrun's RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*.
+    Returns (rank, local_rank, world).  No-op for WORLD_SIZE=1."""
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def shard_envs(num_envs, rank_, world):
+    """Contiguous env shard [lo, hi) of rank_; requires num_envs % world == 0 so every rank runs
+    the same number of minibatch steps (collectives stay matched)."""
+    if num_envs % world != 0:
+        raise ValueError(f"num_envs={num_envs} is not divisible by world size {world}")
+    per = num_envs // world
+    return rank_ * per, (rank_ + 1) * per
+
+
+def allreduce_mean_(flat, world=None):
+    """In-place mean over ranks of one flat tensor (the gradient bucket)."""
+    w = world_size() if world is None else world
+    if w > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.mul_(1.0 / w)
+    return flat
+
+
+def barrier():
+    if world_size() > 1:
+        dist.barrier()

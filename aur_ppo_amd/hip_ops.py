@@ -15,10 +15,20 @@ S_LOSS, S_PG, S_VL, S_ENT, S_OLD_KL, S_KL, S_CLIPFRAC, S_ADV_MEAN, S_ADV_STD = r
 N_SCALARS = 9
 
 
+_runtime_checked = False
+
+
 def _lib_or_raise():
+    global _runtime_checked
     lib = _lib.load()
     if not torch.cuda.is_available():
         raise RuntimeError("aur_ppo_amd.hip_ops needs a gfx950 GPU: the HIP kernels have no CPU fallback")
+    if not _runtime_checked:
+        n = lib.aurppo_device_count()
+        if n != torch.cuda.device_count():
+            raise RuntimeError(f"libaurppo_hip.so sees {n} device(s) but torch sees {torch.cuda.device_count()}: the "
+                               "library is bound to a different HIP runtime than torch (import torch before loading it)")
+        _runtime_checked = True
     return lib
 
 
@@ -109,6 +119,8 @@ class MT19937:
 
     def shuffle_(self, idx):
         """In-place ``np.random.shuffle`` of an int32 device vector."""
+        if idx.numel() == 0:
+            return idx
         _check(_lib.load().aurppo_shuffle_i32(self._h, _ptr(idx, torch.int32), idx.numel(), _stream()),
                "aurppo_shuffle_i32")
         return idx

@@ -1,0 +1,363 @@
+"""``ppo`` -- the trainer of src/ppo.py with its API (``ppo(params).train()``, ``torch_buffer``,
+``run_gae``, ``normal_advantage``, ``advantages``, ``rewards_to_go`` ...) and its numerics, with the
+non-network part of the update on hand-written HIP kernels:
+
+    rollout buffer (T,N,..) --K1 gae--> advantages/returns --K2 shuffle--> E x (B,) indices
+      per minibatch: K3 fused gather -> policy.evaluate (PyTorch-ROCm) -> K4+K5 loss fwd+bwd
+                     -> autograd through the nets -> [RCCL all-reduce] -> K6 clip -> Adam
+
+What differs from the reference on purpose (MI355X-first, results unchanged):
+  * nothing on the update path synchronises with the host: the per-minibatch ``.item()`` calls
+    (src/ppo.py:234,246) become rows of a device-side scalar table read once per update;
+  * all E epoch permutations of an update are generated up front on a side stream (they depend
+    only on the RNG stream), overlapping the rollout / the previous update;
+  * parameters and gradients live in one flat bucket (aur_ppo_amd/flat.py).
+"""
+from __future__ import annotations
+
+import random
+import time
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import dist as D
+from .actor_critic import actor_critic
+from .envs import make_vec_env
+from .flat import FlatBucket
+from .scalars import make_writer
+
+device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
+
+
+class torch_buffer:
+    """Time-major rollout storage (src/ppo.py:20-39): ``states (T,N,*obs)``, ``actions (T,N,*act)``,
+    ``log_probs / rewards / terminals / values (T,N)``; ``flatten`` returns zero-copy views with
+    flat index ``t*N + n``."""
+
+    def __init__(self, observation_shape, action_shape, num_steps, num_envs, device=device):
+        self.observation_shape = tuple(observation_shape)
+        self.action_shape = tuple(action_shape)
+        z = lambda *s: torch.zeros(s, device=device)
+        self.states = z(num_steps, num_envs, *self.observation_shape)
+        self.actions = z(num_steps, num_envs, *self.action_shape)
+        self.log_probs = z(num_steps, num_envs)
+        self.rewards = z(num_steps, num_envs)
+        self.terminals = z(num_steps, num_envs)
+        self.values = z(num_steps, num_envs)
+
+    def flatten(self, returns, advantages):
+        b_obs = self.states.reshape((-1,) + self.observation_shape)
+        b_logprobs = self.log_probs.reshape(-1)
+        b_actions = self.actions.reshape((-1,) + self.action_shape)
+        b_advantages = advantages.reshape(-1)
+        b_returns = returns.reshape(-1)
+        b_values = self.values.reshape(-1)
+        return b_obs, b_logprobs, b_actions, b_advantages, b_returns, b_values
+
+
+class ppo:
+    """``ppo(params)`` as upstream (src/ppo.py:42-83).  Extra, optional ``params`` keys:
+    ``obs_dim`` / ``act_dim`` / ``env_seed`` (Synthetic-* envs), ``log`` (False silences run logs),
+    ``save`` (False skips the final pickle).  ``num_envs`` is the GLOBAL env count; under
+    ``torch.distributed`` each rank keeps ``num_envs / world`` of them (aur_ppo_amd/dist.py).
+
+    ``ops`` is a test seam: the module providing the kernels (default: ``aur_ppo_amd.hip_ops``,
+    which raises without the built HIP library or without a GPU -- there is no fallback).
+    Host-logic tests on a CPU box inject a stand-in built on the oracle; the product never does.
+    """
+
+    def __init__(self, params, ops=None, envs=None):
+        self.params_dict = params
+        self.all_steps = None
+        self.minibatch_size = None
+        for key, value in params.items():
+            if key not in ("batch_size", "minibatch_size"):
+                setattr(self, key, value)
+        if ops is None:
+            from . import hip_ops as ops   # fails loudly when the library is missing
+        self.ops = ops
+        self.device = torch.device(params.get("device", device))
+        self.world = D.world_size()
+        self.rank = D.rank()
+        self.global_num_envs = int(self.num_envs)
+        lo, hi = D.shard_envs(self.global_num_envs, self.rank, self.world)
+        self.num_envs = hi - lo                      # local shard from here on
+        self.env_lo = lo
+        # derived sizes (src/ppo.py:61-64), per rank
+        self.all_steps = self.num_steps * self.num_envs
+        self.batch_size = int(self.num_envs * self.num_steps)
+        self.minibatch_size = int(self.all_steps // self.num_minibatches)
+        assert self.minibatch_size > 0, "num_minibatches exceeds the batch"
+        self.num_updates = self.total_timesteps // (self.batch_size * self.world)
+        self.run_name = f"{self.gym_id}__{self.exp_name}__{self.seed}__{int(time.time())}"
+        p2 = dict(params)
+        p2["rank"] = self.rank
+        self.envs = envs if envs is not None else make_vec_env(self.gym_id, self.num_envs, self.continuous,
+                                                               self.device, p2)
+        self.state_dim = self.envs.single_observation_space.shape
+        if self.continuous:
+            self.action_dim = self.envs.single_action_space.shape
+        else:
+            self.action_dim = self.envs.single_action_space.n
+        self.policy = actor_critic(self.state_dim[0], self.action_dim, self.hidden_dim, self.num_layers,
+                                   self.dropout, self.continuous).to(self.device)
+        if self.world > 1:                           # identical start on every rank
+            for p in self.policy.parameters():
+                torch.distributed.broadcast(p.data, src=0)
+        self.buffer = torch_buffer(self.state_dim, self.envs.single_action_space.shape, self.num_steps,
+                                   self.num_envs, self.device)
+        self.bucket = FlatBucket(self.policy.parameters())
+        self.optimizer = torch.optim.Adam(self.policy.parameters(), lr=self.learning_rate, eps=1e-5)
+        self.total_returns = []
+        self.total_episode_lengths = []
+        self.x_indices = []
+        # device-side machinery of the update
+        self.rng = None            # ops.MT19937, created by seed_all()
+        self._perm_stream = None
+        self._perm_ready = None
+        self._perms = None
+        self._perm_bufs = None
+        self._perm_flip = 0
+        n_steps = self.num_update_epochs * ((self.batch_size + self.minibatch_size - 1) // self.minibatch_size)
+        self._scalars = torch.zeros((n_steps, ops.N_SCALARS), device=self.device)
+        self._norms = torch.zeros(n_steps, device=self.device)
+        self.last_update = None
+        self._probe = None         # bench.py hangs HIP-event pairs around the gather launches here
+
+    # ------------------------------------------------------------------ seeding / shuffle stream
+    def seed_all(self, seed=1):
+        """src/ppo.py:180-184 (seed hard-coded to 1 upstream, F3) + the device twin of numpy's stream."""
+        random.seed(seed)
+        np.random.seed(seed)
+        torch.manual_seed(seed)
+        self.rng = self.ops.MT19937(seed, self.batch_size, self.device)
+        self._perms = None
+
+    def _prefetch_perms(self):
+        """Enqueue the next update's E permutations (src/ppo.py:213-217) on a side stream, into one
+        of two persistent (E, B) int32 buffers (allocated on the main stream, so no cross-stream
+        allocator traffic).  The side stream first waits for everything already enqueued on the
+        main stream -- which includes the last reader of the buffer being overwritten."""
+        if self.rng is None:
+            self.seed_all(1)
+        if self.target_kl is not None:
+            self._rng_snapshot = self.rng.get_state()      # early stop must rewind the stream
+        if self._perm_bufs is None:
+            self._perm_bufs = [torch.empty((self.num_update_epochs, self.batch_size), dtype=torch.int32,
+                                           device=self.device) for _ in range(2)]
+        out = self._perm_bufs[self._perm_flip]
+        self._perm_flip ^= 1
+        if self.device.type != "cuda":
+            self._perms = self.rng.shuffle_epochs(self.batch_size, self.num_update_epochs, out=out)
+            return
+        if self._perm_stream is None:
+            self._perm_stream = torch.cuda.Stream(device=self.device)
+        self._perm_stream.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self._perm_stream):
+            self._perms = self.rng.shuffle_epochs(self.batch_size, self.num_update_epochs, out=out)
+            self._perm_ready = torch.cuda.Event()
+            self._perm_ready.record(self._perm_stream)
+
+    def _take_perms(self):
+        if self._perms is None:
+            self._prefetch_perms()
+        if self._perm_ready is not None:
+            torch.cuda.current_stream(self.device).wait_event(self._perm_ready)
+            self._perm_ready = None
+        perms, self._perms = self._perms, None
+        if self.target_kl is None:
+            self._prefetch_perms()      # next update's shuffles overlap this update's compute
+        return perms
+
+    # ------------------------------------------------------------------ rollout (src/ppo.py:103-123)
+    def make_env(self, gym_id, idx, capture_video):
+        raise NotImplementedError("environments are built by aur_ppo_amd.envs.make_vec_env")
+
+    def rewards_to_go(self, step, next_obs, global_step, writer):
+        with torch.no_grad():
+            action, logprob, _, value = self.policy.evaluate(next_obs.to(self.device))
+            self.buffer.values[step] = value.flatten()
+        self.buffer.actions[step] = action
+        self.buffer.log_probs[step] = logprob
+        if getattr(self.envs, "device_native", False):
+            next_obs, reward, next_done, _, info = self.envs.step(action)
+            self.buffer.rewards[step] = reward.view(-1)
+        else:
+            next_obs, reward, done, _, info = self.envs.step(action.cpu().numpy())
+            self.buffer.rewards[step] = torch.as_tensor(np.asarray(reward), dtype=torch.float32).view(-1)
+            next_obs = torch.as_tensor(np.asarray(next_obs), dtype=torch.float32).to(self.device)
+            next_done = torch.as_tensor(np.asarray(done), dtype=torch.float32).to(self.device)
+        if "final_info" in info.keys():
+            for item in info["final_info"]:
+                if item is not None:
+                    writer.add_scalar("charts/episodic_return", item["episode"]["r"], global_step)
+                    writer.add_scalar("charts/episodic_length", item["episode"]["l"], global_step)
+                    self.total_returns.append(item["episode"]["r"])
+                    self.total_episode_lengths.append(item["episode"]["l"])
+                    self.x_indices.append(global_step)
+                    break
+        return next_obs, next_done
+
+    # ------------------------------------------------------------------ advantages (src/ppo.py:125-166)
+    def run_gae(self, next_value, next_done):
+        b = self.buffer
+        return self.ops.gae(b.rewards, b.values, b.terminals, next_value.contiguous(), next_done.contiguous(),
+                            self.gamma, self.gae_lambda, self.ops.GAE)
+
+    def normal_advantage(self, next_value, next_done):
+        b = self.buffer
+        return self.ops.gae(b.rewards, b.values, b.terminals, next_value.contiguous(), next_done.contiguous(),
+                            self.gamma, self.gae_lambda, self.ops.NORMAL_ADV)
+
+    def advantages(self, next_obs, next_done):
+        with torch.no_grad():
+            next_value = self.policy.value(next_obs)
+            if self.gae:
+                returns, advantages = self.run_gae(next_value, next_done)
+            else:
+                returns, advantages = self.normal_advantage(next_value, next_done)
+        return returns, advantages
+
+    # ------------------------------------------------------------------ update (src/ppo.py:210-273)
+    def update(self, returns, advantages):
+        """E epochs x minibatches of the clipped-surrogate step over the current buffer.  Returns
+        the number of optimizer steps taken; per-step scalars are left in ``self._scalars``."""
+        ops = self.ops
+        b_obs, b_logprobs, b_actions, b_advantages, b_returns, b_values = self.buffer.flatten(returns, advantages)
+        srcs = [b_obs, b_actions, b_logprobs, b_advantages, b_returns, b_values]
+        perms = self._take_perms()
+        vmode = ops.VLOSS_CLIPPED if self.clip_vloss else ops.VLOSS_OLDVALUES   # src/ppo.py:250-261 (F8)
+        B, M = self.batch_size, self.minibatch_size
+        step = 0
+        rng_after_epoch = None
+        for ep in range(self.num_update_epochs):
+            idx_ep = perms[ep]
+            for start in range(0, B, M):
+                mb_inds = idx_ep[start:start + M]
+                if self._probe is not None:
+                    self._probe.begin()
+                obs, act, old_lp, adv, ret, val = ops.gather(mb_inds, srcs)
+                if self._probe is not None:
+                    self._probe.end()
+                _, newlogprob, entropy, newvalue = self.policy.evaluate(obs, act)
+                loss = ops.ppo_loss(newlogprob, newvalue, entropy, old_lp, adv, val, ret, self.clip_coeff,
+                                    self.entropy_coeff, self.value_coeff, self.norm_adv, vmode, self._scalars[step])
+                self.bucket.zero_grad()
+                loss.backward()
+                D.allreduce_mean_(self.bucket.flat_grad, self.world)
+                ops.grad_norm_clip_(self.bucket.flat_grad, self.max_grad_norm, self._norms[step:step + 1])
+                self.optimizer.step()
+                step += 1
+            if self.target_kl is not None:
+                # the reference compares the LAST minibatch's approx_kl (src/ppo.py:271-273)
+                kl = self._scalars[step - 1, ops.S_KL].clone()
+                if self.world > 1:
+                    torch.distributed.all_reduce(kl)
+                    kl /= self.world
+                if float(kl) > self.target_kl:
+                    # epochs after the break never shuffled upstream: rewind the RNG stream to here
+                    self._rewind_rng(ep)
+                    break
+        return step
+
+    def _rewind_rng(self, last_epoch_run):
+        """Early stop at epoch e: upstream has drawn e+1 shuffles this update, we pre-drew E.
+        Re-create the stream position by replaying from the snapshot taken at update start."""
+        key, pos = self._rng_snapshot
+        self.rng.set_state(key, pos)
+        self.rng.shuffle_epochs(self.batch_size, last_epoch_run + 1)
+        self._perms = None
+
+    # ------------------------------------------------------------------ train (src/ppo.py:169-300)
+    def train(self):
+        log = self.params_dict.get("log", True)
+        if getattr(self, "track", False):
+            import wandb
+            wandb.init(project="ppo", sync_tensorboard=True, config=None, name=self.run_name, save_code=True)
+        writer = make_writer(f"runs/{self.run_name}", write=log and self.rank == 0)
+        self.writer = writer
+        writer.add_text("hyperparameters", "|param|value|\n|-|-|\n%s" % (
+            "\n".join([f"|{key}|{str(self.params_dict[key])}|" for key in self.params_dict])))
+        self.seed_all(1)
+        global_step = 0
+        start_time = time.time()
+        next_obs = self.envs.reset(seed=list(range(self.env_lo, self.env_lo + self.num_envs)))[0]
+        next_obs = torch.as_tensor(next_obs, dtype=torch.float32).to(self.device)
+        next_done = torch.zeros(self.num_envs, device=self.device)
+        for update in range(1, self.num_updates + 1):
+            if self.anneal_lr:
+                frac = 1.0 - (update - 1.0) / self.num_updates
+                self.optimizer.param_groups[0]["lr"] = frac * self.learning_rate
+            if self._perms is None:
+                self._prefetch_perms()              # overlaps the rollout below
+            for step in range(0, self.num_steps):
+                global_step += 1 * self.num_envs * self.world
+                self.buffer.states[step] = next_obs
+                self.buffer.terminals[step] = next_done
+                next_obs, next_done = self.rewards_to_go(step, next_obs, global_step, writer)
+            returns, advantages = self.advantages(next_obs, next_done)
+            n_steps = self.update(returns, advantages)
+            self._log_update(writer, returns, n_steps, global_step, start_time)
+        self.envs.close()
+        writer.close()
+        if self.params_dict.get("save", True) and self.rank == 0:
+            torch.save(self.policy, "actor_critic_" + str(self.num_layers) + ".pt")
+        if len(self.total_returns) >= 10 and self.rank == 0 and log:
+            self.plot_episodic_returns(np.array(self.total_returns), np.array(self.x_indices), "episodic returns")
+            self.plot_episodic_returns(np.array(self.total_episode_lengths), np.array(self.x_indices), "episodic lengths")
+        return self.total_returns, self.total_episode_lengths, self.x_indices
+
+    def _log_update(self, writer, returns, n_steps, global_step, start_time):
+        """One host read per update: the scalar table, then the reference's tags (src/ppo.py:277-292)."""
+        ops = self.ops
+        b_values, b_returns = self.buffer.values.reshape(-1), returns.reshape(-1)
+        var_y = b_returns.var(unbiased=False)
+        ev = 1 - (b_returns - b_values).var(unbiased=False) / var_y
+        table = torch.cat([self._scalars[:n_steps].reshape(-1), self._norms[:n_steps], var_y.view(1), ev.view(1)]).cpu()
+        sc = table[:n_steps * ops.N_SCALARS].view(n_steps, ops.N_SCALARS).numpy()
+        var_y, ev = float(table[-2]), float(table[-1])
+        last = sc[-1]                                # logged values are the last minibatch's
+        self.last_update = dict(scalars=sc, grad_norms=table[n_steps * ops.N_SCALARS:-2].numpy(),
+                                explained_variance=(np.nan if var_y == 0 else ev))
+        writer.add_scalar("charts/learning_rate", self.optimizer.param_groups[0]["lr"], global_step)
+        writer.add_scalar("losses/value_loss", last[ops.S_VL], global_step)
+        writer.add_scalar("losses/policy_loss", last[ops.S_PG], global_step)
+        writer.add_scalar("losses/entropy", last[ops.S_ENT], global_step)
+        writer.add_scalar("losses/old_approx_kl", last[ops.S_OLD_KL], global_step)
+        writer.add_scalar("losses/approx_kl", last[ops.S_KL], global_step)
+        writer.add_scalar("losses/clipfrac", float(np.mean(sc[:, ops.S_CLIPFRAC])), global_step)
+        writer.add_scalar("losses/explained_variance", self.last_update["explained_variance"], global_step)
+        writer.add_scalar("charts/SPS", int(global_step / (time.time() - start_time)), global_step)
+
+    # ------------------------------------------------------------------ plotting (src/ppo.py:303-321)
+    def plot(self, loss, x_indices):
+        import matplotlib.pyplot as plt
+        plt.plot(np.array(x_indices), loss)
+        plt.xlabel("Timestep")
+        plt.ylabel("Total returns")
+        plt.title("Episode Length over time")
+        plt.show()
+
+    def moving_average(self, data, window_size):
+        return np.convolve(data, np.ones(window_size) / window_size, mode="valid")
+
+    def plot_episodic_returns(self, episodic_returns, x_indices, title, window_size=10):
+        import os
+        import matplotlib
+        matplotlib.use("Agg")
+        import matplotlib.pyplot as plt
+        smoothed = self.moving_average(episodic_returns, window_size)
+        plt.figure()
+        plt.plot(x_indices, episodic_returns, label="Episodic Returns")
+        plt.plot(x_indices[window_size - 1:], smoothed, label=f"Moving Average (Window Size = {window_size})", color="red")
+        plt.title("Episodic Returns with Moving Average for " + self.gym_id)
+        plt.xlabel("Timestep")
+        plt.ylabel("Return")
+        plt.legend()
+        out_dir = "../plots" if os.path.isdir("../plots") else "plots"
+        os.makedirs(out_dir, exist_ok=True)
+        plt.savefig(f"{out_dir}/{title}_num_layers_{self.num_layers}_dropout_{self.dropout}_num_envs_"
+                    f"{self.global_num_envs}_num_mb_{self.num_minibatches}.png")
+        plt.close()

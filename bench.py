@@ -1,0 +1,201 @@
+#!/usr/bin/env python
+"""env-steps/s through GAE + PPO update (BASELINE.json metric) on N MI355X GPUs of one node.
+
+A "step" is one full pass of the hot path over one synthetic rollout batch that is already
+resident in HBM: bootstrap value -> K1 GAE -> K2 E epoch shuffles -> E x minibatches of
+{K3 gather, policy/value forward, K4+K5 loss fwd+bwd, backward, [RCCL all-reduce], K6 clip,
+Adam}.  Workload at --gpus 1 is the configuration the metric is quoted on (num_envs=4096, T=128,
+obs 64, act 6, E=4, 4 minibatches, 2x64 tanh MLP); with N GPUs every rank keeps --envs-per-gpu
+envs (weak scaling, env-sharded, one gradient all-reduce per optimizer step).
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--envs-per-gpu", type=int, default=4096)
+    ap.add_argument("--num-steps", type=int, default=128)
+    ap.add_argument("--obs-dim", type=int, default=64)
+    ap.add_argument("--act-dim", type=int, default=6)
+    ap.add_argument("--epochs", type=int, default=4)
+    ap.add_argument("--minibatches", type=int, default=4)
+    ap.add_argument("--cpu-baseline-updates", type=int, default=2, help="timed CPU-oracle updates (0 = skip)")
+    ap.add_argument("--no-probe", action="store_true", help="do not time the gather kernel with HIP events")
+    return ap.parse_args()
+
+
+class EventProbe:
+    """HIP-event pairs around every launch of the dominant kernel (K3 gather), recorded on the
+    stream it is launched on (torch's current stream)."""
+
+    def __init__(self):
+        self.pairs = []
+        self.on = False
+
+    def begin(self):
+        if self.on:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self._b = e
+
+    def end(self):
+        if self.on:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.pairs.append((self._b, e))
+
+    def mean_ms(self):
+        return float(np.mean([b.elapsed_time(e) for b, e in self.pairs])) if self.pairs else None
+
+
+def hyper(args, world):
+    return dict(gym_id="Synthetic-v0", seed=1.0, num_steps=args.num_steps, gae=True,
+                total_timesteps=args.num_steps * args.envs_per_gpu * world, anneal_lr=False, gae_lambda=0.95,
+                num_update_epochs=args.epochs, num_envs=args.envs_per_gpu * world, num_minibatches=args.minibatches,
+                entropy_coeff=0.0, value_coeff=0.5, clip_coeff=0.2, clip_vloss=True, max_grad_norm=0.5,
+                target_kl=None, norm_adv=True, capture_video=False, hidden_dim=64, continuous=True,
+                learning_rate=3e-4, exp_name="bench", num_layers=2, dropout=0.0, gamma=0.99, track=False,
+                log=False, save=False, obs_dim=args.obs_dim, act_dim=args.act_dim)
+
+
+def synth_buffers(T, N, D, A, seed):
+    """SURVEY section 8d synthetic rollout tensors (CPU generator so the CPU baseline sees the same data)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return dict(states=torch.randn(T, N, D, generator=g), actions=torch.randn(T, N, A, generator=g),
+                values=torch.randn(T, N, generator=g), rewards=torch.randn(T, N, generator=g),
+                terminals=(torch.rand(T, N, generator=g) < 0.02).float(),
+                next_obs=torch.randn(N, D, generator=g), next_done=(torch.rand(N, generator=g) < 0.02).float())
+
+
+def cpu_baseline(args, data, init_sd, n_updates):
+    """The oracle's reference-faithful CPU update (same op sequence as src/ppo.py:125-142,213-269)
+    timed on this box's host cores -- a reported baseline, never the measured product path."""
+    from oracle import ppo_oracle as O
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    hp = hyper(args, 1)
+    T, N = args.num_steps, args.envs_per_gpu
+    net = O.make_actor_critic(args.obs_dim, (args.act_dim,), 64, 2, True)
+    net.load_state_dict(init_sd)
+    opt = torch.optim.Adam(net.parameters(), lr=hp["learning_rate"], eps=1e-5)
+    buf = {k: data[k] for k in ("states", "actions", "log_probs", "rewards", "terminals", "values")}
+    rng = np.random.RandomState(1)
+    O.reference_update(net, opt, buf, data["next_obs"], data["next_done"], hp, rng, collect=False)   # warm-up
+    t0 = time.perf_counter()
+    for _ in range(n_updates):
+        O.reference_update(net, opt, buf, data["next_obs"], data["next_done"], hp, rng, collect=False)
+    dt = time.perf_counter() - t0
+    return {"value": T * N * n_updates / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"1 warm-up + {n_updates} timed full updates (N={N}, T={T}, E={args.epochs}, "
+                      f"{args.minibatches} minibatches) of oracle.reference_update, torch CPU fp32, {cores} threads, "
+                      f"{dt / n_updates:.2f} s/update"}
+
+
+def main():
+    args = parse()
+    from aur_ppo_amd import dist as D
+    rank, local_rank, world = D.init_from_env()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    from aur_ppo_amd.ppo import ppo
+    torch.manual_seed(1)
+    hp = hyper(args, world)
+    hp["device"] = dev
+    agent = ppo(hp)
+    T, N, Dm, A = args.num_steps, agent.num_envs, args.obs_dim, args.act_dim
+    data = synth_buffers(T, N, Dm, A, 1234 + rank)
+    init_sd = {k: v.detach().cpu().clone() for k, v in agent.policy.state_dict().items()}
+    for k in ("states", "actions", "values", "rewards", "terminals"):
+        getattr(agent.buffer, k).copy_(data[k])
+    next_obs, next_done = data["next_obs"].to(dev), data["next_done"].to(dev)
+    with torch.no_grad():   # old log-probs = the policy's own, at init weights (ratio ~ 1 at epoch 0)
+        _, lp, _, _ = agent.policy.evaluate(agent.buffer.states.view(-1, Dm), agent.buffer.actions.view(-1, A))
+        agent.buffer.log_probs.copy_(lp.view(T, N))
+    data["log_probs"] = agent.buffer.log_probs.cpu()
+    agent.seed_all(1)
+    probe = EventProbe()
+    agent._probe = None if args.no_probe else probe
+
+    def one_step():
+        returns, advantages = agent.advantages(next_obs, next_done)
+        agent.update(returns, advantages)
+
+    for _ in range(args.warmup):
+        one_step()
+    probe.on = True
+    D.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    torch.cuda.synchronize()
+    D.barrier()
+    dt = time.perf_counter() - t0
+    probe.on = False
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t)
+    sc = agent._scalars.cpu().numpy()
+    assert np.isfinite(sc).all(), "non-finite loss scalars in the timed region"
+    if rank != 0:
+        return
+    env_steps = world * N * T * args.steps
+    M = agent.minibatch_size
+    gather_bytes = M * (8 * Dm + 8 * A + 36)          # idx + 6 streams read + written
+    g_ms = probe.mean_ms()
+    roofline = None
+    if g_ms:
+        ach = gather_bytes / (g_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "gather_pmc.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": "k_gather", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "bytes_per_launch": gather_bytes, "avg_launch_us": round(g_ms * 1e3, 2),
+                    "launches_timed": len(probe.pairs)}
+    out = {"metric": "env-steps/sec through GAE+PPO-update at num_envs=4096,T=128; 1/2/4/8 GPU",
+           "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"synthetic continuous obs_dim={Dm} act_dim={A}, num_envs={N}/GPU x {world} GPU, "
+                                  f"T={T}, E={args.epochs}, {args.minibatches} minibatches/epoch (M={M}), 2x64 tanh "
+                                  "MLP actor+critic, Adam, random-init weights",
+                      "global_num_envs": N * world, "num_steps": T, "parallelism": f"env-shard dp{world}"},
+           "roofline": roofline}
+    if world == 1 and args.cpu_baseline_updates > 0:
+        out["cpu_baseline"] = cpu_baseline(args, data, init_sd, args.cpu_baseline_updates)
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,108 @@
+"""GPU: the trainer on the real HIP path vs traces of the real reference and vs the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import load, synth_rollout
+
+pytestmark = pytest.mark.gpu
+
+
+def _agent(hp):
+    from aur_ppo_amd.ppo import ppo
+    assert torch.cuda.is_available()
+    return ppo(hp)        # default ops = the HIP module
+
+
+@pytest.mark.parametrize("name", ["cfg1_discrete", "cfg2_continuous", "cfg3_normal_adv_tail"])
+def test_gpu_update_reproduces_reference_trace(name):
+    z = load("trace.npz")
+    hp = dict(eval(str(z[f"{name}/params"])))
+    init = {k[len(name) + 6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(f"{name}/init/")}
+    hp.update(gym_id="Synthetic-v0", obs_dim=init["actor.net.0.weight"].shape[1],
+              act_dim=init["actor.net.4.weight"].shape[0], log=False, save=False)
+    agent = _agent(hp)
+    agent.policy.load_state_dict(init)
+    agent.bucket.check_attached()
+    agent.seed_all(1)
+    U = int(z[f"{name}/num_updates"][0])
+    ref_sc = z[f"{name}/scalars"]
+    from aur_ppo_amd.scalars import ScalarRecorder
+    w = ScalarRecorder()
+    for u in range(U):
+        agent.optimizer.param_groups[0]["lr"] = (1.0 - u / U) * hp["learning_rate"]
+        for k in ("states", "actions", "log_probs", "rewards", "terminals", "values"):
+            getattr(agent.buffer, k).copy_(torch.from_numpy(z[f"{name}/u{u}/{k}"]))
+        ret, adv = agent.advantages(torch.from_numpy(z[f"{name}/u{u}/next_obs"]).cuda(),
+                                    torch.from_numpy(z[f"{name}/u{u}/next_done"]).cuda())
+        np.testing.assert_allclose(adv.cpu().numpy(), z[f"{name}/u{u}/advantages"], rtol=0, atol=1e-5)
+        np.testing.assert_allclose(ret.cpu().numpy(), z[f"{name}/u{u}/returns"], rtol=0, atol=1e-5)
+        n = agent.update(ret, adv)
+        agent._log_update(w, ret, n, (u + 1) * agent.batch_size, 0.0)
+        got = [w.series(t)[-1][1] for t in ("losses/value_loss", "losses/policy_loss", "losses/entropy",
+                                            "losses/old_approx_kl", "losses/approx_kl", "losses/clipfrac",
+                                            "losses/explained_variance")]
+        # losses within 1e-5 (north_star); clipfrac is a count ratio and may move by one sample
+        np.testing.assert_allclose(got[:5], ref_sc[u][1:6], rtol=1e-4, atol=1e-5)
+        assert abs(got[5] - ref_sc[u][6]) <= 1.5 / agent.minibatch_size
+        np.testing.assert_allclose(got[6], ref_sc[u][7], rtol=1e-4, atol=1e-5)
+    for k, v in agent.policy.state_dict().items():
+        np.testing.assert_allclose(v.cpu().numpy(), z[f"{name}/final/{k}"], rtol=1e-4, atol=2e-6, err_msg=k)
+
+
+def test_gpu_update_vs_cpu_oracle_update_config2_shape():
+    """Synthetic continuous obs 64 / act 6 (BASELINE configs[1] shape at N=64): one full update on
+    the HIP path vs the oracle's reference-faithful CPU update, same init, same buffers, seed 1."""
+    from oracle import ppo_oracle as O
+    T, N, Dm, A = 32, 64, 64, 6
+    hp = dict(gym_id="Synthetic-v0", seed=1.0, num_steps=T, gae=True, total_timesteps=T * N, anneal_lr=False,
+              gae_lambda=0.95, num_update_epochs=4, num_envs=N, num_minibatches=4, entropy_coeff=0.0,
+              value_coeff=0.5, clip_coeff=0.2, clip_vloss=True, max_grad_norm=0.5, target_kl=None, norm_adv=True,
+              capture_video=False, hidden_dim=64, continuous=True, learning_rate=3e-4, exp_name="t", num_layers=2,
+              dropout=0.0, gamma=0.99, track=False, log=False, save=False, obs_dim=Dm, act_dim=A)
+    torch.manual_seed(1)
+    agent = _agent(hp)
+    cpu_net = O.make_actor_critic(Dm, (A,), 64, 2, True)
+    cpu_net.load_state_dict({k: v.cpu() for k, v in agent.policy.state_dict().items()})
+    d = synth_rollout(T, N, Dm, A)
+    with torch.no_grad():   # log-probs of the stored actions under the initial policy, as in real training
+        _, lp, _, _ = cpu_net.evaluate(torch.from_numpy(d["states"]).view(-1, Dm), torch.from_numpy(d["actions"]).view(-1, A))
+    d["log_probs"] = (lp.view(T, N) + 0.05 * torch.randn(T, N)).numpy()
+    buf = {k: torch.from_numpy(d[k]) for k in ("states", "actions", "log_probs", "rewards", "terminals", "values")}
+    for k, v in buf.items():
+        getattr(agent.buffer, k).copy_(v)
+    agent.seed_all(1)
+    ret, adv = agent.advantages(torch.from_numpy(d["next_obs"]).cuda(), torch.from_numpy(d["next_done"]).cuda())
+    n = agent.update(ret, adv)
+    torch.cuda.synchronize()
+    opt = torch.optim.Adam(cpu_net.parameters(), lr=3e-4, eps=1e-5)
+    res = O.reference_update(cpu_net, opt, buf, torch.from_numpy(d["next_obs"]), torch.from_numpy(d["next_done"]), hp,
+                             np.random.RandomState(1))
+    np.testing.assert_allclose(adv.cpu().numpy(), res["advantages"].numpy(), rtol=0, atol=1e-5)
+    np.testing.assert_allclose(ret.cpu().numpy(), res["returns"].numpy(), rtol=0, atol=1e-5)
+    got = agent._scalars[:n].cpu().numpy()
+    assert n == 16
+    cols = [0, 1, 2, 3, 4, 5, 7, 8]   # all but clipfrac
+    np.testing.assert_allclose(got[:, cols], res["scalars"][:, cols], rtol=1e-4, atol=1e-5)
+    assert np.abs(got[:, 6] - res["scalars"][:, 6]).max() <= 1.5 / agent.minibatch_size
+    for (k, v), (_, v2) in zip(agent.policy.state_dict().items(), cpu_net.state_dict().items()):
+        np.testing.assert_allclose(v.cpu().numpy(), v2.numpy(), rtol=1e-4, atol=2e-6, err_msg=k)
+
+
+def test_gpu_train_end_to_end_synthetic_and_cartpole():
+    hp = dict(gym_id="Synthetic-v0", seed=1.0, num_steps=32, gae=True, total_timesteps=3 * 32 * 256, anneal_lr=True,
+              gae_lambda=0.95, num_update_epochs=4, num_envs=256, num_minibatches=4, entropy_coeff=0.0,
+              value_coeff=0.5, clip_coeff=0.2, clip_vloss=True, max_grad_norm=0.5, target_kl=None, norm_adv=True,
+              capture_video=False, hidden_dim=64, continuous=True, learning_rate=3e-4, exp_name="t", num_layers=2,
+              dropout=0.0, gamma=0.99, track=False, log=False, save=False)
+    a = _agent(hp)
+    a.train()
+    assert a.last_update["scalars"].shape == (16, 9) and np.isfinite(a.last_update["scalars"]).all()
+    assert np.isfinite(a.last_update["grad_norms"]).all()
+    # plumbing config (BASELINE configs[0]): CartPole-v1, 4 envs, discrete; a short run must improve
+    hp2 = dict(hp, gym_id="CartPole-v1", num_envs=4, num_steps=128, total_timesteps=512 * 60, continuous=False,
+               entropy_coeff=0.01, learning_rate=2.5e-4)
+    b = _agent(hp2)
+    r, l, x = b.train()
+    assert len(r) > 20
+    assert np.mean(r[-10:]) > 2.0 * np.mean(r[:10]), (np.mean(r[:10]), np.mean(r[-10:]))
