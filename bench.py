@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--epochs", type=int, default=4)
     ap.add_argument("--minibatches", type=int, default=4)
     ap.add_argument("--cpu-baseline-updates", type=int, default=2, help="timed CPU-oracle updates (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = usable cores, <=16)")
     ap.add_argument("--no-probe", action="store_true", help="do not time the gather kernel with HIP events")
     return ap.parse_args()
 
@@ -89,11 +90,28 @@ def synth_buffers(T, N, D, A, seed):
                 next_obs=torch.randn(N, D, generator=g), next_done=(torch.rand(N, generator=g) < 0.02).float())
 
 
+def usable_cores(cap=16):
+    """Host threads this process may really use: affinity mask, cgroup CPU quota, and the GPU box's
+    per-GPU CPU share (16) -- oversubscribing a quota'd cgroup makes the baseline meaninglessly slow."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, min(n, cap))
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def cpu_baseline(args, data, init_sd, n_updates):
     """The oracle's reference-faithful CPU update (same op sequence as src/ppo.py:125-142,213-269)
     timed on this box's host cores -- a reported baseline, never the measured product path."""
     from oracle import ppo_oracle as O
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = args.cpu_threads or usable_cores()
     torch.set_num_threads(cores)
     hp = hyper(args, 1)
     T, N = args.num_steps, args.envs_per_gpu
@@ -102,15 +120,21 @@ def cpu_baseline(args, data, init_sd, n_updates):
     opt = torch.optim.Adam(net.parameters(), lr=hp["learning_rate"], eps=1e-5)
     buf = {k: data[k] for k in ("states", "actions", "log_probs", "rewards", "terminals", "values")}
     rng = np.random.RandomState(1)
-    O.reference_update(net, opt, buf, data["next_obs"], data["next_done"], hp, rng, collect=False)   # warm-up
     t0 = time.perf_counter()
-    for _ in range(n_updates):
-        O.reference_update(net, opt, buf, data["next_obs"], data["next_done"], hp, rng, collect=False)
-    dt = time.perf_counter() - t0
+    O.reference_update(net, opt, buf, data["next_obs"], data["next_done"], hp, rng, collect=False)   # warm-up
+    warm = time.perf_counter() - t0
+    log(f"cpu baseline warm-up update: {warm:.2f} s on {cores} threads")
+    if warm > 20.0:          # keep the default run bounded: the warm-up itself is the sample
+        n_updates, dt, note = 1, warm, "1 full update (cold; longer than the 20 s budget so used as the sample)"
+    else:
+        t0 = time.perf_counter()
+        for _ in range(n_updates):
+            O.reference_update(net, opt, buf, data["next_obs"], data["next_done"], hp, rng, collect=False)
+        dt = time.perf_counter() - t0
+        note = f"1 warm-up + {n_updates} timed full updates"
     return {"value": T * N * n_updates / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"1 warm-up + {n_updates} timed full updates (N={N}, T={T}, E={args.epochs}, "
-                      f"{args.minibatches} minibatches) of oracle.reference_update, torch CPU fp32, {cores} threads, "
-                      f"{dt / n_updates:.2f} s/update"}
+            "sample": f"{note} (N={N}, T={T}, E={args.epochs}, {args.minibatches} minibatches) of "
+                      f"oracle.reference_update, torch CPU fp32, {cores} threads, {dt / n_updates:.2f} s/update"}
 
 
 def main():
@@ -143,8 +167,11 @@ def main():
         returns, advantages = agent.advantages(next_obs, next_done)
         agent.update(returns, advantages)
 
+    log(f"rank {rank}/{world}: setup done, {args.warmup} warm-up steps")
     for _ in range(args.warmup):
         one_step()
+    torch.cuda.synchronize()
+    log("warm-up done, timing")
     probe.on = True
     D.barrier()
     torch.cuda.synchronize()
@@ -155,6 +182,7 @@ def main():
     D.barrier()
     dt = time.perf_counter() - t0
     probe.on = False
+    log(f"timed region: {dt:.3f} s for {args.steps} steps")
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)

@@ -408,6 +408,12 @@ def gen_trace(ref_ppo):
         ("cfg3_normal_adv_tail", dict(obs_dim=3, continuous=True, act_dim=2, env_seed=7),
          dict(num_envs=5, num_steps=10, total_timesteps=2 * 50, continuous=True, gae=False, num_minibatches=4,
               clip_vloss=False, num_update_epochs=2)),
+        # same ragged-tail / discounted-return path, but with the clipped value loss: with clip_vloss=False
+        # upstream regresses the critic to its own old values (src/ppo.py:261), a gradient of pure rounding
+        # noise, so critic parity is only well-defined in this variant
+        ("cfg4_normal_adv_tail_clipv", dict(obs_dim=3, continuous=True, act_dim=2, env_seed=8),
+         dict(num_envs=5, num_steps=10, total_timesteps=3 * 50, continuous=True, gae=False, num_minibatches=4,
+              clip_vloss=True, num_update_epochs=3)),
     ]
     for name, envc, over in cfgs:
         SynthVecEnv.current = envc

@@ -153,7 +153,7 @@ def test_oracle_actor_critic_matches_reference_evaluate_and_init():
 
 
 # ------------------------------------------------------------------ whole update (src/ppo.py:192-292)
-@pytest.mark.parametrize("name", ["cfg1_discrete", "cfg2_continuous", "cfg3_normal_adv_tail"])
+@pytest.mark.parametrize("name", ["cfg1_discrete", "cfg2_continuous", "cfg3_normal_adv_tail", "cfg4_normal_adv_tail_clipv"])
 def test_reference_update_restatement_reproduces_reference_train_trace(name):
     torch.set_num_threads(1)
     z = load("trace.npz")

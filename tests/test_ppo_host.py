@@ -51,7 +51,7 @@ def test_api_surface_matches_reference():
     assert b[0].data_ptr() == a.buffer.states.data_ptr()      # views, not copies
 
 
-@pytest.mark.parametrize("name", ["cfg1_discrete", "cfg2_continuous", "cfg3_normal_adv_tail"])
+@pytest.mark.parametrize("name", ["cfg1_discrete", "cfg2_continuous", "cfg3_normal_adv_tail", "cfg4_normal_adv_tail_clipv"])
 def test_trainer_update_reproduces_reference_trace(name):
     torch.set_num_threads(1)
     z = load("trace.npz")
