@@ -9,10 +9,10 @@ LIB_PATH = os.path.join(_HERE, "libaurppo_hip.so")
 
 # every symbol include/aurppo.h declares (tests/test_abi.py checks the header against this list)
 SYMBOLS = (
-    "aurppo_version", "aurppo_last_error", "aurppo_device_count", "aurppo_gae_f32",
+    "aurppo_version", "aurppo_last_error", "aurppo_device_count", "aurppo_gae_f32", "aurppo_gae_pack_f32",
     "aurppo_mt19937_create", "aurppo_mt19937_destroy", "aurppo_mt19937_seed", "aurppo_mt19937_get_state",
     "aurppo_mt19937_set_state", "aurppo_arange_i32", "aurppo_shuffle_i32", "aurppo_shuffle_epochs_i32",
-    "aurppo_gather_f32", "aurppo_loss_workspace_bytes", "aurppo_loss_fwd_bwd_f32",
+    "aurppo_gather_f32", "aurppo_loss_workspace_bytes", "aurppo_loss_fwd_bwd_f32", "aurppo_loss_fwd_bwd_packed_f32",
     "aurppo_clip_workspace_bytes", "aurppo_grad_norm_clip_f32",
 )
 
@@ -42,6 +42,7 @@ def load() -> C.CDLL:
     lib.aurppo_last_error.restype = C.c_char_p
     lib.aurppo_device_count.restype = i32
     lib.aurppo_gae_f32.argtypes = [vp] * 7 + [i32, i32, f64, f64, i32, vp]
+    lib.aurppo_gae_pack_f32.argtypes = [vp] * 9 + [i32, i32, f64, f64, i32, vp]
     lib.aurppo_mt19937_create.argtypes = [C.POINTER(vp), C.c_uint32, i32, vp]
     lib.aurppo_mt19937_destroy.argtypes = [vp]
     lib.aurppo_mt19937_seed.argtypes = [vp, C.c_uint32, vp]
@@ -54,6 +55,7 @@ def load() -> C.CDLL:
     lib.aurppo_loss_workspace_bytes.argtypes = [i32]
     lib.aurppo_loss_workspace_bytes.restype = C.c_size_t
     lib.aurppo_loss_fwd_bwd_f32.argtypes = [vp] * 7 + [i32, f64, f64, f64, i32, i32] + [vp] * 6
+    lib.aurppo_loss_fwd_bwd_packed_f32.argtypes = [vp] * 4 + [i32, f64, f64, f64, i32, i32] + [vp] * 6
     lib.aurppo_clip_workspace_bytes.argtypes = [C.c_int64]
     lib.aurppo_clip_workspace_bytes.restype = C.c_size_t
     lib.aurppo_grad_norm_clip_f32.argtypes = [vp, C.c_int64, f64, vp, vp, vp]

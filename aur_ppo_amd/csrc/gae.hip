@@ -24,7 +24,8 @@ __global__ __launch_bounds__(256) void k_gae(const float* __restrict__ rewards, 
                                              const float* __restrict__ terminals,
                                              const float* __restrict__ next_value,
                                              const float* __restrict__ next_done, float* __restrict__ adv,
-                                             float* __restrict__ ret, int T, int N, float g, float gl, int mode) {
+                                             float* __restrict__ ret, const float* __restrict__ log_probs,
+                                             float4* __restrict__ rec, int T, int N, float g, float gl, int mode) {
     constexpr int ROWS = 256 / TILE_N;
     __shared__ float s_d[kSlab][TILE_N];  // d[t], then X[t]
     __shared__ float s_c[kSlab][TILE_N];  // c[t]
@@ -104,13 +105,13 @@ __global__ __launch_bounds__(256) void k_gae(const float* __restrict__ rewards, 
                 const size_t at = (size_t)(t_lo + tt) * N + n;
                 const float x = s_d[tt][e];
                 const float vt = s_v[tt][e];
-                if (normal) {
-                    ret[at] = x;
-                    adv[at] = x - vt;
-                } else {
-                    adv[at] = x;
-                    ret[at] = x + vt;
-                }
+                const float a_ = normal ? x - vt : x;
+                const float r_ = normal ? x : x + vt;
+                adv[at] = a_;
+                ret[at] = r_;
+                // optional per-sample record {old_logp, A, R, V}: one 16-B request per sample for the
+                // minibatch gather instead of four divergent 4-B ones
+                if (rec) rec[at] = make_float4(log_probs[at], a_, r_, vt);
             }
         }
         __syncthreads();
@@ -119,11 +120,12 @@ __global__ __launch_bounds__(256) void k_gae(const float* __restrict__ rewards, 
 
 }  // namespace
 
-extern "C" int aurppo_gae_f32(const float* rewards, const float* values, const float* terminals,
-                              const float* next_value, const float* next_done, float* advantages, float* returns,
-                              int T, int N, double gamma, double lam, int mode, void* stream) {
+static int gae_launch(const float* rewards, const float* values, const float* terminals, const float* next_value,
+                      const float* next_done, float* advantages, float* returns, const float* log_probs, float* rec,
+                      int T, int N, double gamma, double lam, int mode, void* stream) {
     AURPPO_REQUIRE(rewards && values && terminals && next_value && next_done && advantages && returns, AURPPO_EINVAL,
                    "aurppo_gae_f32: null pointer");
+    AURPPO_REQUIRE(!rec || aligned_to(rec, 16), AURPPO_EINVAL, "aurppo_gae_pack_f32: rec not 16-byte aligned");
     AURPPO_REQUIRE(mode >= 0 && mode <= 2, AURPPO_EINVAL, "aurppo_gae_f32: bad mode %d", mode);
     AURPPO_REQUIRE(T > 0 && N > 0, AURPPO_ESHAPE, "aurppo_gae_f32: T=%d N=%d must be positive", T, N);
     const float g = (float)gamma;
@@ -132,14 +134,30 @@ extern "C" int aurppo_gae_f32(const float* rewards, const float* values, const f
     // Narrow tiles put a workgroup on every CU at N=4096; widen them only when N alone fills the chip.
     if (N >= 16384) {
         hipLaunchKernelGGL(k_gae<64>, dim3((N + 63) / 64), dim3(256), 0, s, rewards, values, terminals, next_value,
-                           next_done, advantages, returns, T, N, g, gl, mode);
+                           next_done, advantages, returns, log_probs, reinterpret_cast<float4*>(rec), T, N, g, gl, mode);
     } else if (N >= 8192) {
         hipLaunchKernelGGL(k_gae<32>, dim3((N + 31) / 32), dim3(256), 0, s, rewards, values, terminals, next_value,
-                           next_done, advantages, returns, T, N, g, gl, mode);
+                           next_done, advantages, returns, log_probs, reinterpret_cast<float4*>(rec), T, N, g, gl, mode);
     } else {
         hipLaunchKernelGGL(k_gae<16>, dim3((N + 15) / 16), dim3(256), 0, s, rewards, values, terminals, next_value,
-                           next_done, advantages, returns, T, N, g, gl, mode);
+                           next_done, advantages, returns, log_probs, reinterpret_cast<float4*>(rec), T, N, g, gl, mode);
     }
     AURPPO_LAUNCH_CHECK("k_gae");
     return AURPPO_OK;
+}
+
+extern "C" int aurppo_gae_f32(const float* rewards, const float* values, const float* terminals,
+                              const float* next_value, const float* next_done, float* advantages, float* returns,
+                              int T, int N, double gamma, double lam, int mode, void* stream) {
+    return gae_launch(rewards, values, terminals, next_value, next_done, advantages, returns, nullptr, nullptr, T, N,
+                      gamma, lam, mode, stream);
+}
+
+extern "C" int aurppo_gae_pack_f32(const float* rewards, const float* values, const float* terminals,
+                                   const float* next_value, const float* next_done, const float* log_probs,
+                                   float* advantages, float* returns, float* rec, int T, int N, double gamma,
+                                   double lam, int mode, void* stream) {
+    AURPPO_REQUIRE(log_probs && rec, AURPPO_EINVAL, "aurppo_gae_pack_f32: null pointer");
+    return gae_launch(rewards, values, terminals, next_value, next_done, advantages, returns, log_probs, rec, T, N,
+                      gamma, lam, mode, stream);
 }

@@ -24,12 +24,14 @@ struct LossWs {
     double part[kMaxBlocks][6];
 };
 
+// STRIDE = 1: adv is a plain (M,) array; STRIDE = 4: adv points at field 1 of a packed (M,4) record
+template <int STRIDE>
 __global__ __launch_bounds__(kThreads) void k_adv_stats(const float* __restrict__ adv, int M,
                                                         double (*__restrict__ stats)[2]) {
     __shared__ double sc[2][kNW];
     double s = 0.0, q = 0.0;
     for (int i = blockIdx.x * kThreads + threadIdx.x; i < M; i += gridDim.x * kThreads) {
-        const double a = (double)adv[i];
+        const double a = (double)adv[(size_t)i * STRIDE];
         s += a;
         q += a * a;
     }
@@ -48,6 +50,8 @@ struct LossParams {
     int norm_adv, vloss_mode;
 };
 
+// PACKED: oldlogp points at a (M,4) record {old_logp, adv, ret, old_v}; adv/oldv/ret are ignored
+template <bool PACKED>
 __global__ __launch_bounds__(kThreads) void k_loss(const float* __restrict__ newlogp,
                                                    const float* __restrict__ oldlogp,
                                                    const float* __restrict__ adv, const float* __restrict__ newv,
@@ -81,9 +85,21 @@ __global__ __launch_bounds__(kThreads) void k_loss(const float* __restrict__ new
     const float g_ent = -p.ent_coef * invM;
     double a_pg = 0.0, a_vl = 0.0, a_ent = 0.0, a_okl = 0.0, a_kl = 0.0, a_cf = 0.0;
     for (int i = blockIdx.x * kThreads + threadIdx.x; i < p.M; i += gridDim.x * kThreads) {
-        const float lr = newlogp[i] - oldlogp[i];
+        float ol_, a_raw, vo, R;
+        if (PACKED) {
+            const float4 r4 = reinterpret_cast<const float4*>(oldlogp)[i];
+            ol_ = r4.x;
+            a_raw = r4.y;
+            R = r4.z;
+            vo = r4.w;
+        } else {
+            ol_ = oldlogp[i];
+            a_raw = adv[i];
+            R = ret[i];
+            vo = oldv[i];
+        }
+        const float lr = newlogp[i] - ol_;
         const float ratio = expf(lr);
-        const float a_raw = adv[i];
         const float an = p.norm_adv ? (a_raw - mean) / denom : a_raw;
         a_okl += (double)(-lr);
         a_kl += (double)((ratio - 1.0f) - lr);
@@ -99,8 +115,6 @@ __global__ __launch_bounds__(kThreads) void k_loss(const float* __restrict__ new
         g_newlogp[i] = dpg * ratio;
         // value term
         const float v = newv[i];
-        const float vo = oldv[i];
-        const float R = ret[i];
         float dvl;
         if (p.vloss_mode == AURPPO_VLOSS_CLIPPED) {
             const float du = v - R;
@@ -174,14 +188,15 @@ extern "C" size_t aurppo_loss_workspace_bytes(int M) {
     return sizeof(LossWs);
 }
 
-extern "C" int aurppo_loss_fwd_bwd_f32(const float* newlogp, const float* oldlogp, const float* adv,
-                                       const float* newv, const float* oldv, const float* ret,
-                                       const float* entropy, int M, double clip, double ent_coef, double vf_coef,
-                                       int norm_adv, int vloss_mode, float* out_scalars, float* g_newlogp,
-                                       float* g_newv, float* g_entropy, void* workspace, void* stream) {
+static int loss_launch(bool packed, const float* newlogp, const float* oldlogp, const float* adv, const float* newv,
+                       const float* oldv, const float* ret, const float* entropy, int M, double clip, double ent_coef,
+                       double vf_coef, int norm_adv, int vloss_mode, float* out_scalars, float* g_newlogp,
+                       float* g_newv, float* g_entropy, void* workspace, void* stream) {
     AURPPO_REQUIRE(newlogp && oldlogp && adv && newv && oldv && ret && entropy && out_scalars && g_newlogp && g_newv &&
                        g_entropy && workspace,
                    AURPPO_EINVAL, "aurppo_loss_fwd_bwd_f32: null pointer");
+    AURPPO_REQUIRE(!packed || aligned_to(oldlogp, 16), AURPPO_EINVAL,
+                   "aurppo_loss_fwd_bwd_packed_f32: rec not 16-byte aligned");
     AURPPO_REQUIRE(aligned_to(workspace, 16), AURPPO_EINVAL, "aurppo_loss_fwd_bwd_f32: workspace not 16-byte aligned");
     AURPPO_REQUIRE(vloss_mode >= 0 && vloss_mode <= 2, AURPPO_EINVAL, "aurppo_loss_fwd_bwd_f32: bad vloss_mode %d",
                    vloss_mode);
@@ -201,12 +216,37 @@ extern "C" int aurppo_loss_fwd_bwd_f32(const float* newlogp, const float* oldlog
     int blocks = (M + kThreads * 4 - 1) / (kThreads * 4);
     if (blocks > kMaxBlocks - 1) blocks = kMaxBlocks - 1;
     p.n_stat_blocks = blocks;
-    hipLaunchKernelGGL(k_adv_stats, dim3(blocks), dim3(kThreads), 0, s, adv, M, ws->stats);
-    AURPPO_LAUNCH_CHECK("k_adv_stats");
-    hipLaunchKernelGGL(k_loss, dim3(blocks), dim3(kThreads), 0, s, newlogp, oldlogp, adv, newv, oldv, ret, entropy, p,
-                       g_newlogp, g_newv, g_entropy, ws);
+    if (packed) {
+        hipLaunchKernelGGL(k_adv_stats<4>, dim3(blocks), dim3(kThreads), 0, s, adv, M, ws->stats);
+        AURPPO_LAUNCH_CHECK("k_adv_stats");
+        hipLaunchKernelGGL(k_loss<true>, dim3(blocks), dim3(kThreads), 0, s, newlogp, oldlogp, adv, newv, oldv, ret,
+                           entropy, p, g_newlogp, g_newv, g_entropy, ws);
+    } else {
+        hipLaunchKernelGGL(k_adv_stats<1>, dim3(blocks), dim3(kThreads), 0, s, adv, M, ws->stats);
+        AURPPO_LAUNCH_CHECK("k_adv_stats");
+        hipLaunchKernelGGL(k_loss<false>, dim3(blocks), dim3(kThreads), 0, s, newlogp, oldlogp, adv, newv, oldv, ret,
+                           entropy, p, g_newlogp, g_newv, g_entropy, ws);
+    }
     AURPPO_LAUNCH_CHECK("k_loss");
     hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(kThreads), 0, s, ws, blocks, p, out_scalars);
     AURPPO_LAUNCH_CHECK("k_loss_final");
     return AURPPO_OK;
+}
+
+extern "C" int aurppo_loss_fwd_bwd_f32(const float* newlogp, const float* oldlogp, const float* adv,
+                                       const float* newv, const float* oldv, const float* ret,
+                                       const float* entropy, int M, double clip, double ent_coef, double vf_coef,
+                                       int norm_adv, int vloss_mode, float* out_scalars, float* g_newlogp,
+                                       float* g_newv, float* g_entropy, void* workspace, void* stream) {
+    return loss_launch(false, newlogp, oldlogp, adv, newv, oldv, ret, entropy, M, clip, ent_coef, vf_coef, norm_adv,
+                       vloss_mode, out_scalars, g_newlogp, g_newv, g_entropy, workspace, stream);
+}
+
+extern "C" int aurppo_loss_fwd_bwd_packed_f32(const float* newlogp, const float* newv, const float* entropy,
+                                              const float* rec, int M, double clip, double ent_coef, double vf_coef,
+                                              int norm_adv, int vloss_mode, float* out_scalars, float* g_newlogp,
+                                              float* g_newv, float* g_entropy, void* workspace, void* stream) {
+    AURPPO_REQUIRE(rec, AURPPO_EINVAL, "aurppo_loss_fwd_bwd_packed_f32: null rec");
+    return loss_launch(true, newlogp, rec, rec + 1, newv, rec + 3, rec + 2, entropy, M, clip, ent_coef, vf_coef,
+                       norm_adv, vloss_mode, out_scalars, g_newlogp, g_newv, g_entropy, workspace, stream);
 }

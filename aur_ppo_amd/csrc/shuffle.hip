@@ -95,38 +95,45 @@ __global__ __launch_bounds__(kFyThreads) void k_fy_targets(uint32_t* __restrict_
         const bool have = (pos + tid) < kMtN;
         const uint32_t y = have ? mt_temper(mt[pos + tid]) : 0u;
         // fixed point of: acc_p = [ (y_p & mask(i_p)) <= i_p ],  i_p = i_cur - #{q<p : acc_q}
+        auto decide = [&](int i_mine, uint32_t& v_out) -> bool {
+            if (!(have && i_mine >= 1)) return false;
+            uint32_t mask = (uint32_t)i_mine;
+            mask |= mask >> 1;
+            mask |= mask >> 2;
+            mask |= mask >> 4;
+            mask |= mask >> 8;
+            mask |= mask >> 16;
+            v_out = y & mask;
+            return v_out <= (uint32_t)i_mine;
+        };
         int excl = tid;  // first guess: every earlier draw accepted
-        bool acc = false;
         uint32_t v = 0;
-        int my_i = 0;
+        int my_i = i_cur - excl;
+        bool acc = decide(my_i, v);
+        int total = 0;
         for (int it = 0;; ++it) {
-            my_i = i_cur - excl;
-            acc = false;
-            if (have && my_i >= 1) {
-                uint32_t mask = (uint32_t)my_i;
-                mask |= mask >> 1;
-                mask |= mask >> 2;
-                mask |= mask >> 4;
-                mask |= mask >> 8;
-                mask |= mask >> 16;
-                v = y & mask;
-                acc = v <= (uint32_t)my_i;
-            }
             const unsigned long long bal = __ballot(acc);
             if (lane == 0) s_wcnt[wave] = __popcll(bal);
             if (tid == 0) s_changed[(it + 1) & 1] = 0;
             __syncthreads();
             int base = 0;
-            for (int w = 0; w < wave; ++w) base += s_wcnt[w];
-            const int new_excl = base + __popcll(bal & ((1ull << lane) - 1ull));
-            if (new_excl != excl) s_changed[it & 1] = 1;
-            excl = new_excl;
+            total = 0;
+#pragma unroll
+            for (int w = 0; w < kFyThreads / kWave; ++w) {  // independent LDS reads, no serial chain
+                const int c = s_wcnt[w];
+                total += c;
+                base += (w < wave) ? c : 0;
+            }
+            excl = base + __popcll(bal & ((1ull << lane) - 1ull));
+            // re-decide under the prefix these decisions imply; if nobody flips, they are the solution
+            my_i = i_cur - excl;
+            const bool acc2 = decide(my_i, v);
+            if (acc2 != acc) s_changed[it & 1] = 1;
+            acc = acc2;
             __syncthreads();
             if (!s_changed[it & 1]) break;
         }
         if (acc) j[my_i] = (int32_t)v;
-        int total = 0;
-        for (int w = 0; w < kFyThreads / kWave; ++w) total += s_wcnt[w];
         int consumed = kMtN - pos;
         if (total >= i_cur) {  // the shuffle ends inside this block: find the draw that filled i = 1
             if (acc && my_i == 1) s_last = tid + 1;

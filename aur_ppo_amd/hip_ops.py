@@ -61,8 +61,10 @@ def _workspace(kind, nbytes, device):
 
 
 # ------------------------------------------------------------------ K1
-def gae(rewards, values, terminals, next_value, next_done, gamma, lam, mode=GAE, out=None):
-    """``ppo.run_gae`` / ``normal_advantage`` (src/ppo.py:125-157).  Returns (returns, advantages)."""
+def gae(rewards, values, terminals, next_value, next_done, gamma, lam, mode=GAE, out=None, log_probs=None, rec=None):
+    """``ppo.run_gae`` / ``normal_advantage`` (src/ppo.py:125-157).  Returns (returns, advantages).
+    With ``log_probs`` (T,N) and ``rec`` (T*N,4) the kernel also writes the per-sample record
+    {old_logp, A, R, V} the packed gather / loss path consumes."""
     lib = _lib_or_raise()
     T, N = rewards.shape
     if values.shape != (T, N) or terminals.shape != (T, N) or next_value.numel() != N or next_done.numel() != N:
@@ -72,6 +74,13 @@ def gae(rewards, values, terminals, next_value, next_done, gamma, lam, mode=GAE,
         adv, ret = torch.empty_like(rewards), torch.empty_like(rewards)
     else:
         ret, adv = out
+    if rec is not None:
+        if log_probs is None or log_probs.shape != (T, N) or rec.numel() != 4 * T * N:
+            raise ValueError("gae: rec needs log_probs (T,N) and rec (T*N,4)")
+        _check(lib.aurppo_gae_pack_f32(_ptr(rewards), _ptr(values), _ptr(terminals), _ptr(next_value), _ptr(next_done),
+                                       _ptr(log_probs), _ptr(adv), _ptr(ret), _ptr(rec), T, N, float(gamma),
+                                       float(lam), int(mode), _stream()), "aurppo_gae_pack_f32")
+        return ret, adv
     _check(lib.aurppo_gae_f32(_ptr(rewards), _ptr(values), _ptr(terminals), _ptr(next_value), _ptr(next_done),
                               _ptr(adv), _ptr(ret), T, N, float(gamma), float(lam), int(mode), _stream()),
            "aurppo_gae_f32")
@@ -183,6 +192,46 @@ def loss_fwd_bwd(newlogp, oldlogp, adv, newv, oldv, ret, entropy, clip, ent_coef
                                        int(bool(norm_adv)), int(vloss_mode), _ptr(out_scalars), _ptr(g_lp), _ptr(g_v),
                                        _ptr(g_e), C.c_void_p(ws.data_ptr()), _stream()), "aurppo_loss_fwd_bwd_f32")
     return out_scalars, g_lp, g_v, g_e
+
+
+def loss_fwd_bwd_packed(newlogp, newv, entropy, rec, clip, ent_coef, vf_coef, norm_adv=True, vloss_mode=VLOSS_CLIPPED,
+                        out_scalars=None):
+    """As ``loss_fwd_bwd`` with the old-side inputs as a gathered (M,4) record {old_logp, adv, ret, old_v}."""
+    lib = _lib_or_raise()
+    M = newlogp.numel()
+    if newv.numel() != M or entropy.numel() != M or rec.numel() != 4 * M:
+        raise ValueError("loss_fwd_bwd_packed: size mismatch")
+    dev = newlogp.device
+    if out_scalars is None:
+        out_scalars = torch.empty(N_SCALARS, dtype=torch.float32, device=dev)
+    g_lp, g_v, g_e = (torch.empty(M, dtype=torch.float32, device=dev) for _ in range(3))
+    ws = _workspace("loss", lib.aurppo_loss_workspace_bytes(M), dev)
+    _check(lib.aurppo_loss_fwd_bwd_packed_f32(_ptr(newlogp), _ptr(newv), _ptr(entropy), _ptr(rec), M, float(clip),
+                                              float(ent_coef), float(vf_coef), int(bool(norm_adv)), int(vloss_mode),
+                                              _ptr(out_scalars), _ptr(g_lp), _ptr(g_v), _ptr(g_e),
+                                              C.c_void_p(ws.data_ptr()), _stream()), "aurppo_loss_fwd_bwd_packed_f32")
+    return out_scalars, g_lp, g_v, g_e
+
+
+class PPOLossPackedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, newlogp, newv, entropy, rec, clip, ent_coef, vf_coef, norm_adv, vloss_mode, out_scalars):
+        sc, g_lp, g_v, g_e = loss_fwd_bwd_packed(newlogp.detach().contiguous(), newv.detach().reshape(-1).contiguous(),
+                                                 entropy.detach().contiguous(), rec, clip, ent_coef, vf_coef, norm_adv,
+                                                 vloss_mode, out_scalars)
+        ctx.save_for_backward(g_lp, g_v, g_e)
+        ctx.v_shape = newv.shape
+        return sc[S_LOSS].clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        g_lp, g_v, g_e = ctx.saved_tensors
+        return (g_lp * grad_out, (g_v * grad_out).view(ctx.v_shape), g_e * grad_out) + (None,) * 7
+
+
+def ppo_loss_packed(newlogp, newv, entropy, rec, clip, ent_coef, vf_coef, norm_adv=True, vloss_mode=VLOSS_CLIPPED,
+                    out_scalars=None):
+    return PPOLossPackedFn.apply(newlogp, newv, entropy, rec, clip, ent_coef, vf_coef, norm_adv, vloss_mode, out_scalars)
 
 
 class PPOLossFn(torch.autograd.Function):

@@ -124,6 +124,8 @@ class ppo:
         self._scalars = torch.zeros((n_steps, ops.N_SCALARS), device=self.device)
         self._norms = torch.zeros(n_steps, device=self.device)
         self.last_update = None
+        self._rec = None           # (B,4) per-sample record written by K1
+        self._rec_of = None
         self._probe = None         # bench.py hangs HIP-event pairs around the gather launches here
 
     # ------------------------------------------------------------------ seeding / shuffle stream
@@ -201,15 +203,22 @@ class ppo:
         return next_obs, next_done
 
     # ------------------------------------------------------------------ advantages (src/ppo.py:125-166)
-    def run_gae(self, next_value, next_done):
+    def _gae(self, next_value, next_done, mode):
+        """K1 + pack: besides (returns, advantages) the kernel leaves the per-sample record
+        {old_logp, A, R, V} in ``self._rec`` for the packed gather / loss path of ``update``."""
         b = self.buffer
-        return self.ops.gae(b.rewards, b.values, b.terminals, next_value.contiguous(), next_done.contiguous(),
-                            self.gamma, self.gae_lambda, self.ops.GAE)
+        if self._rec is None:
+            self._rec = torch.empty((self.batch_size, 4), device=self.device)
+        ret, adv = self.ops.gae(b.rewards, b.values, b.terminals, next_value.contiguous(), next_done.contiguous(),
+                                self.gamma, self.gae_lambda, mode, log_probs=b.log_probs, rec=self._rec)
+        self._rec_of = (ret, adv)
+        return ret, adv
+
+    def run_gae(self, next_value, next_done):
+        return self._gae(next_value, next_done, self.ops.GAE)
 
     def normal_advantage(self, next_value, next_done):
-        b = self.buffer
-        return self.ops.gae(b.rewards, b.values, b.terminals, next_value.contiguous(), next_done.contiguous(),
-                            self.gamma, self.gae_lambda, self.ops.NORMAL_ADV)
+        return self._gae(next_value, next_done, self.ops.NORMAL_ADV)
 
     def advantages(self, next_obs, next_done):
         with torch.no_grad():
@@ -226,7 +235,10 @@ class ppo:
         the number of optimizer steps taken; per-step scalars are left in ``self._scalars``."""
         ops = self.ops
         b_obs, b_logprobs, b_actions, b_advantages, b_returns, b_values = self.buffer.flatten(returns, advantages)
-        srcs = [b_obs, b_actions, b_logprobs, b_advantages, b_returns, b_values]
+        # packed path when (returns, advantages) are the tensors K1 just produced; otherwise (a caller
+        # handing in its own) the six separate streams of buffer.flatten()
+        packed = self._rec_of is not None and self._rec_of[0] is returns and self._rec_of[1] is advantages
+        srcs = [b_obs, b_actions, self._rec] if packed else [b_obs, b_actions, b_logprobs, b_advantages, b_returns, b_values]
         perms = self._take_perms()
         vmode = ops.VLOSS_CLIPPED if self.clip_vloss else ops.VLOSS_OLDVALUES   # src/ppo.py:250-261 (F8)
         B, M = self.batch_size, self.minibatch_size
@@ -238,12 +250,18 @@ class ppo:
                 mb_inds = idx_ep[start:start + M]
                 if self._probe is not None:
                     self._probe.begin()
-                obs, act, old_lp, adv, ret, val = ops.gather(mb_inds, srcs)
+                mb = ops.gather(mb_inds, srcs)
                 if self._probe is not None:
                     self._probe.end()
-                _, newlogprob, entropy, newvalue = self.policy.evaluate(obs, act)
-                loss = ops.ppo_loss(newlogprob, newvalue, entropy, old_lp, adv, val, ret, self.clip_coeff,
-                                    self.entropy_coeff, self.value_coeff, self.norm_adv, vmode, self._scalars[step])
+                _, newlogprob, entropy, newvalue = self.policy.evaluate(mb[0], mb[1])
+                if packed:
+                    loss = ops.ppo_loss_packed(newlogprob, newvalue, entropy, mb[2], self.clip_coeff,
+                                               self.entropy_coeff, self.value_coeff, self.norm_adv, vmode,
+                                               self._scalars[step])
+                else:
+                    loss = ops.ppo_loss(newlogprob, newvalue, entropy, mb[2], mb[3], mb[5], mb[4], self.clip_coeff,
+                                        self.entropy_coeff, self.value_coeff, self.norm_adv, vmode,
+                                        self._scalars[step])
                 self.bucket.zero_grad()
                 loss.backward()
                 D.allreduce_mean_(self.bucket.flat_grad, self.world)

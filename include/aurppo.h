@@ -77,6 +77,15 @@ int aurppo_gae_f32(const float* rewards, const float* values, const float* termi
                    float* advantages, float* returns,                                  /* (T,N) out */
                    int T, int N, double gamma, double lam, int mode, void* stream);
 
+/* K1 + pack: as aurppo_gae_f32, and additionally writes the per-sample record
+ *   rec[(t*N+n)*4 + {0,1,2,3}] = { log_probs[t,n], A[t,n], R[t,n], V[t,n] }   ((T*N, 4), 16-B aligned)
+ * i.e. the four per-sample scalars buffer.flatten() hands to the update (src/ppo.py:32-39) laid out
+ * so that the minibatch gather fetches them with ONE 16-byte request per sample.                   */
+int aurppo_gae_pack_f32(const float* rewards, const float* values, const float* terminals,
+                        const float* next_value, const float* next_done, const float* log_probs,
+                        float* advantages, float* returns, float* rec, int T, int N, double gamma,
+                        double lam, int mode, void* stream);
+
 /* ---- K2: numpy-legacy MT19937 + Fisher-Yates shuffle --------------------------------------
  * Replaces np.random.seed(seed) (src/ppo.py:182) and np.random.shuffle(b_inds) (src/ppo.py:217,
  * src/robot_ppo.py:338).  Bit-exact with numpy's RandomState: init_genrand seeding, one 32-bit
@@ -122,6 +131,14 @@ int aurppo_loss_fwd_bwd_f32(const float* newlogp, const float* oldlogp, const fl
                             const float* entropy, int M, double clip, double ent_coef, double vf_coef,
                             int norm_adv, int vloss_mode, float* out_scalars, float* g_newlogp,
                             float* g_newv, float* g_entropy, void* workspace, void* stream);
+
+/* Same computation with the old-side inputs as a gathered (M,4) record {old_logp, adv, ret, old_v}
+ * (rows of aurppo_gae_pack_f32's rec, picked by aurppo_gather_f32 with row_elems = 4).              */
+int aurppo_loss_fwd_bwd_packed_f32(const float* newlogp, const float* newv, const float* entropy,
+                                   const float* rec, int M, double clip, double ent_coef,
+                                   double vf_coef, int norm_adv, int vloss_mode, float* out_scalars,
+                                   float* g_newlogp, float* g_newv, float* g_entropy, void* workspace,
+                                   void* stream);
 
 /* ---- K6: global-norm gradient clip over one flat bucket -------------------------------------
  * Replaces nn.utils.clip_grad_norm_(params, max_norm) (src/ppo.py:268; src/robot_ppo.py:401):

@@ -14,10 +14,13 @@ S_LOSS, S_PG, S_VL, S_ENT, S_OLD_KL, S_KL, S_CLIPFRAC, S_ADV_MEAN, S_ADV_STD = r
 N_SCALARS = 9
 
 
-def gae(rewards, values, terminals, next_value, next_done, gamma, lam, mode=GAE, out=None):
+def gae(rewards, values, terminals, next_value, next_done, gamma, lam, mode=GAE, out=None, log_probs=None, rec=None):
     ret, adv = O.gae(rewards.numpy(), values.numpy(), terminals.numpy(), next_value.numpy(), next_done.numpy(),
                      gamma, lam, mode)
-    return torch.from_numpy(ret), torch.from_numpy(adv)
+    ret, adv = torch.from_numpy(ret), torch.from_numpy(adv)
+    if rec is not None:
+        rec.copy_(torch.stack([log_probs.reshape(-1), adv.reshape(-1), ret.reshape(-1), values.reshape(-1)], 1))
+    return ret, adv
 
 
 class MT19937:
@@ -76,6 +79,12 @@ def ppo_loss(newlogp, newv, entropy, oldlogp, adv, oldv, ret, clip, ent_coef, vf
              vloss_mode=VLOSS_CLIPPED, out_scalars=None):
     return _Loss.apply(newlogp, newv, entropy, oldlogp, adv, oldv, ret, clip, ent_coef, vf_coef, norm_adv, vloss_mode,
                        out_scalars)
+
+
+def ppo_loss_packed(newlogp, newv, entropy, rec, clip, ent_coef, vf_coef, norm_adv=True, vloss_mode=VLOSS_CLIPPED,
+                    out_scalars=None):
+    return _Loss.apply(newlogp, newv, entropy, rec[:, 0], rec[:, 1], rec[:, 3], rec[:, 2], clip, ent_coef, vf_coef,
+                       norm_adv, vloss_mode, out_scalars)
 
 
 def grad_norm_clip_(flat_grads, max_norm, out_norm=None):

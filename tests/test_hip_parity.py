@@ -316,3 +316,30 @@ def test_kernels_run_on_current_stream_and_capture_into_a_graph(H):
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(adv, expect)
+
+
+# ---------------------------------------------------------------------------------- packed record path
+def test_gae_pack_record_and_packed_loss_match_unpacked(H, CO):
+    T, N = 128, 1024
+    d = synth_rollout(T, N, 4, 2)
+    r, v, dn, lp = dev(d["rewards"]), dev(d["values"]), dev(d["terminals"]), dev(d["log_probs"])
+    nv, nd = dev(d["next_value"]), dev(d["next_done"])
+    rec = torch.empty(T * N, 4, device="cuda")
+    ret, adv = H.gae(r, v, dn, nv, nd, 0.99, 0.95, log_probs=lp, rec=rec)
+    ret0, adv0 = H.gae(r, v, dn, nv, nd, 0.99, 0.95)
+    assert torch.equal(ret, ret0) and torch.equal(adv, adv0)
+    assert torch.equal(rec, torch.stack([lp.view(-1), adv.view(-1), ret.view(-1), v.view(-1)], 1))
+    # gather the record as one float4 stream and feed the packed loss: identical to the 7-stream call
+    M = 4096
+    idx = torch.randperm(T * N, device="cuda")[:M].int()
+    (rec_mb,) = H.gather(idx, [rec])
+    assert torch.equal(rec_mb, rec[idx.long()])
+    newlp = rec_mb[:, 0] + 0.1 * torch.randn(M, device="cuda")
+    newv = rec_mb[:, 3] + 0.2 * torch.randn(M, device="cuda")
+    ent = torch.rand(M, device="cuda") + 1
+    for mode in (0, 1, 2):
+        a = H.loss_fwd_bwd_packed(newlp, newv, ent, rec_mb, 0.2, 0.01, 0.5, True, mode)
+        b = H.loss_fwd_bwd(newlp, rec_mb[:, 0].contiguous(), rec_mb[:, 1].contiguous(), newv, rec_mb[:, 3].contiguous(),
+                           rec_mb[:, 2].contiguous(), ent, 0.2, 0.01, 0.5, True, mode)
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)

@@ -121,3 +121,18 @@ def test_gpu_train_end_to_end_synthetic_and_cartpole():
     r, l, x = b.train()
     assert len(r) > 20
     assert np.mean(r[-10:]) > 2.0 * np.mean(r[:10]), (np.mean(r[:10]), np.mean(r[-10:]))
+
+
+def test_split_batch_linear_matches_nn_linear():
+    from aur_ppo_amd.nets import _Linear
+    torch.manual_seed(0)
+    a, b = _Linear(64, 64).cuda(), torch.nn.Linear(64, 64).cuda()
+    b.load_state_dict(a.state_dict())
+    x = torch.randn(16384, 64, device="cuda")
+    xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+    w = torch.randn(16384, 64, device="cuda")
+    (a(xa) * w).sum().backward()
+    (b(xb) * w).sum().backward()
+    torch.testing.assert_close(xa.grad, xb.grad, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(a.weight.grad, b.weight.grad, rtol=2e-5, atol=2e-4)   # 16384-term fp32 sums
+    torch.testing.assert_close(a.bias.grad, b.bias.grad, rtol=2e-5, atol=2e-4)
