@@ -167,9 +167,17 @@ extern "C" int aurppo_gather_f32(const int32_t* idx, int M, const float* const* 
         AURPPO_REQUIRE(row_elems_h[s] >= 1, AURPPO_ESHAPE, "aurppo_gather_f32: row_elems[%d]=%d", s, row_elems_h[s]);
     }
     if (M == 0) return AURPPO_OK;
-    static const int kUnroll = env_int("AURPPO_GATHER_UNROLL", 4);     // tuning knobs (experiments);
-    static const int kRowsOverride = env_int("AURPPO_GATHER_ROWS", 0);  // defaults = measured best
-    const int unroll = (kUnroll == 1 || kUnroll == 2 || kUnroll == 8) ? kUnroll : 4;
+    // Tuning knobs (experiments only).  Measured on MI355X at M=131072, D=64 (profiles/r01): one row
+    // slot per lane (UNROLL 1, 16-row tiles, 8192 workgroups at full occupancy) beats deeper unrolls
+    // (rocprof: 24.2 us vs 26.4 / 28.3 us for UNROLL 2 / 4); a persistent variant that prefetched the
+    // next tile's indices measured no better (24.8-27.9 us) and was dropped.  Rows wider than one lane
+    // group (images) need the 4-deep unroll to keep loads in flight inside their chunk loop.
+    static const int kUnroll = env_int("AURPPO_GATHER_UNROLL", 0);
+    static const int kRowsOverride = env_int("AURPPO_GATHER_ROWS", 0);
+    int widest = 1;
+    for (int s = 0; s < n_streams; ++s) widest = row_elems_h[s] > widest ? row_elems_h[s] : widest;
+    int unroll = widest > 256 ? 4 : 1;
+    if (kUnroll == 1 || kUnroll == 2 || kUnroll == 4 || kUnroll == 8) unroll = kUnroll;
     hipStream_t st = (hipStream_t)stream;
 
     // Scalar streams ride along with the first launch; row streams go out kMaxRowStreams at a time.

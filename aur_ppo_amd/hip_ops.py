@@ -151,9 +151,11 @@ def arange_i32(n, device):
 
 
 # ------------------------------------------------------------------ K3
-def gather(idx, srcs, outs=None):
+def gather(idx, srcs, outs=None, probe=None):
     """One fused launch for ``[s[idx] for s in srcs]`` (src/ppo.py:219-220,225,236,251-257).
-    ``srcs``: flattened buffer tensors (B, ...) sharing dim 0; ``idx``: int32 (M,)."""
+    ``srcs``: flattened buffer tensors (B, ...) sharing dim 0; ``idx``: int32 (M,).
+    ``probe``: optional object whose ``begin()``/``end()`` are called immediately around the C call
+    (bench.py records HIP events there, so host-side argument marshalling is not timed)."""
     lib = _lib_or_raise()
     M = idx.numel()
     n = len(srcs)
@@ -169,7 +171,13 @@ def gather(idx, srcs, outs=None):
     for t in list(srcs) + list(outs):
         _ptr(t)
     row_a = (C.c_int * n)(*row)
-    _check(lib.aurppo_gather_f32(_ptr(idx, torch.int32), M, src_a, dst_a, row_a, n, _stream()), "aurppo_gather_f32")
+    idx_p, st = _ptr(idx, torch.int32), _stream()
+    if probe is not None:
+        probe.begin()
+    rc = lib.aurppo_gather_f32(idx_p, M, src_a, dst_a, row_a, n, st)
+    if probe is not None:
+        probe.end()
+    _check(rc, "aurppo_gather_f32")
     return outs
 
 

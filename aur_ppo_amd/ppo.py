@@ -248,11 +248,7 @@ class ppo:
             idx_ep = perms[ep]
             for start in range(0, B, M):
                 mb_inds = idx_ep[start:start + M]
-                if self._probe is not None:
-                    self._probe.begin()
-                mb = ops.gather(mb_inds, srcs)
-                if self._probe is not None:
-                    self._probe.end()
+                mb = ops.gather(mb_inds, srcs, probe=self._probe) if self._probe is not None else ops.gather(mb_inds, srcs)
                 _, newlogprob, entropy, newvalue = self.policy.evaluate(mb[0], mb[1])
                 if packed:
                     loss = ops.ppo_loss_packed(newlogprob, newvalue, entropy, mb[2], self.clip_coeff,

@@ -134,5 +134,7 @@ def test_split_batch_linear_matches_nn_linear():
     (a(xa) * w).sum().backward()
     (b(xb) * w).sum().backward()
     torch.testing.assert_close(xa.grad, xb.grad, rtol=1e-5, atol=1e-6)
-    torch.testing.assert_close(a.weight.grad, b.weight.grad, rtol=2e-5, atol=2e-4)   # 16384-term fp32 sums
-    torch.testing.assert_close(a.bias.grad, b.bias.grad, rtol=2e-5, atol=2e-4)
+    # 16384-term fp32 sums in a different order: compare at the scale of the result
+    scale = float(b.weight.grad.abs().max())
+    assert float((a.weight.grad - b.weight.grad).abs().max()) <= 2e-5 * scale
+    assert float((a.bias.grad - b.bias.grad).abs().max()) <= 2e-5 * float(b.bias.grad.abs().max())

@@ -44,6 +44,12 @@ if "gather" in what:
     for label, rot in (("hot", 1), ("cold", nset)):
         med, mn = timeit(lambda i: H.gather(perms[i % 4][(i % 4) * M:(i % 4 + 1) * M] if False else perms[i % 4][:M], sets[i % rot], outs[i % 2]))
         out[f"gather_{label}"] = dict(us=med, min_us=mn, GBs=nbytes / med / 1e3, frac=nbytes / med / 1e3 / 8000)
+    # packed layout: obs + actions + one (B,4) record instead of four scalar streams
+    psets = [[st[0], st[1], torch.randn(B, 4, device=dev)] for st in sets]
+    pouts = [[torch.empty((M,) + tuple(s.shape[1:]), device=dev) for s in psets[0]] for _ in range(2)]
+    for label, rot in (("hot", 1), ("cold", nset)):
+        med, mn = timeit(lambda i: H.gather(perms[i % 4][:M], psets[i % rot], pouts[i % 2]))
+        out[f"gather_packed_{label}"] = dict(us=med, min_us=mn, GBs=nbytes / med / 1e3, frac=nbytes / med / 1e3 / 8000)
     # obs-only, to separate the wide stream from the narrow ones
     med, mn = timeit(lambda i: H.gather(perms[i % 4][:M], sets[i % nset][:1], outs[i % 2][:1]))
     out["gather_obs_only_cold"] = dict(us=med, GBs=M * (8 * D + 4) / med / 1e3)
