@@ -109,7 +109,15 @@ class ppo:
         self.buffer = torch_buffer(self.state_dim, self.envs.single_action_space.shape, self.num_steps,
                                    self.num_envs, self.device)
         self.bucket = FlatBucket(self.policy.parameters())
-        self.optimizer = torch.optim.Adam(self.policy.parameters(), lr=self.learning_rate, eps=1e-5)
+        # Adam(eps=1e-5) as upstream (src/ppo.py:80).  On the GPU it is built capturable with the learning
+        # rate in a device scalar, so the whole update can be replayed as one hipGraph while the linear
+        # anneal (src/ppo.py:195-198) still changes it between updates.
+        if self.device.type == "cuda":
+            self._lr_tensor = torch.tensor(float(self.learning_rate), device=self.device)
+            self.optimizer = torch.optim.Adam(self.policy.parameters(), eps=1e-5, capturable=True, lr=self._lr_tensor)
+        else:
+            self._lr_tensor = None
+            self.optimizer = torch.optim.Adam(self.policy.parameters(), lr=self.learning_rate, eps=1e-5)
         self.total_returns = []
         self.total_episode_lengths = []
         self.x_indices = []
@@ -124,9 +132,33 @@ class ppo:
         self._scalars = torch.zeros((n_steps, ops.N_SCALARS), device=self.device)
         self._norms = torch.zeros(n_steps, device=self.device)
         self.last_update = None
+        self._probe_outs = None
+        self._graph = None         # captured update (hipGraph), see update()
+        self._graph_state = 0      # 0: next update runs eagerly (warm-up), 1: capture, 2: replay
+        self._perm_static = None
+        self.use_graph = bool(params.get("hip_graph", True)) and self.device.type == "cuda" and self.world == 1
         self._rec = None           # (B,4) per-sample record written by K1
         self._rec_of = None
         self._probe = None         # bench.py hangs HIP-event pairs around the gather launches here
+
+    def set_lr(self, lr):
+        g = self.optimizer.param_groups[0]
+        if self._lr_tensor is not None:
+            self._lr_tensor.fill_(float(lr))
+            g["lr"] = self._lr_tensor
+        else:
+            g["lr"] = float(lr)
+
+    def _adopt_lr(self):
+        """Upstream writes ``optimizer.param_groups[0]["lr"] = lrnow`` (src/ppo.py:198).  If a caller did
+        that, move the value into the device scalar the (possibly captured) Adam step reads."""
+        g = self.optimizer.param_groups[0]
+        if self._lr_tensor is not None and g["lr"] is not self._lr_tensor:
+            self._lr_tensor.fill_(float(g["lr"]))
+            g["lr"] = self._lr_tensor
+
+    def get_lr(self):
+        return float(self.optimizer.param_groups[0]["lr"])
 
     # ------------------------------------------------------------------ seeding / shuffle stream
     def seed_all(self, seed=1):
@@ -232,18 +264,44 @@ class ppo:
     # ------------------------------------------------------------------ update (src/ppo.py:210-273)
     def update(self, returns, advantages):
         """E epochs x minibatches of the clipped-surrogate step over the current buffer.  Returns
-        the number of optimizer steps taken; per-step scalars are left in ``self._scalars``."""
+        the number of optimizer steps taken; per-step scalars are left in ``self._scalars``.
+
+        On one GPU without ``target_kl`` the whole update (all gathers, forward/backward passes, loss
+        kernels, clips and Adam steps -- ~1750 launches at the BASELINE size) is captured once into a
+        hipGraph and replayed: update 1 runs eagerly (it also creates the optimizer state), update 2
+        is captured, later updates replay.  The graph reads the permutations from a static buffer."""
+        self._adopt_lr()
+        packed = self._rec_of is not None and self._rec_of[0] is returns and self._rec_of[1] is advantages
+        perms = self._take_perms()
+        graphable = self.use_graph and packed and self.target_kl is None and self._probe is None
+        if not graphable:
+            return self._update_body(returns, advantages, perms, packed)
+        if self._graph_state == 0:
+            self._graph_state = 1
+            return self._update_body(returns, advantages, perms, packed)
+        if self._perm_static is None:
+            self._perm_static = torch.empty_like(perms)
+        self._perm_static.copy_(perms)
+        if self._graph_state == 1:
+            # the packed body reads only static storage: the rollout buffer, self._rec, self._perm_static
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._graph_steps = self._update_body(returns, advantages, self._perm_static, packed)
+            self._graph = g
+            self._graph_state = 2
+        self._graph.replay()
+        return self._graph_steps
+
+    def _update_body(self, returns, advantages, perms, packed):
         ops = self.ops
         b_obs, b_logprobs, b_actions, b_advantages, b_returns, b_values = self.buffer.flatten(returns, advantages)
         # packed path when (returns, advantages) are the tensors K1 just produced; otherwise (a caller
         # handing in its own) the six separate streams of buffer.flatten()
-        packed = self._rec_of is not None and self._rec_of[0] is returns and self._rec_of[1] is advantages
         srcs = [b_obs, b_actions, self._rec] if packed else [b_obs, b_actions, b_logprobs, b_advantages, b_returns, b_values]
-        perms = self._take_perms()
         vmode = ops.VLOSS_CLIPPED if self.clip_vloss else ops.VLOSS_OLDVALUES   # src/ppo.py:250-261 (F8)
         B, M = self.batch_size, self.minibatch_size
         step = 0
-        rng_after_epoch = None
         for ep in range(self.num_update_epochs):
             idx_ep = perms[ep]
             for start in range(0, B, M):
@@ -276,6 +334,18 @@ class ppo:
                     break
         return step
 
+    def probe_gather(self, probe):
+        """One stand-alone launch of exactly the update's first-minibatch gather (same index slice,
+        same sources) with ``probe.begin()/end()`` around the C call.  bench.py uses it to time K3 with
+        HIP events inside the timed region when the update itself runs as a hipGraph (events cannot be
+        read back from inside a captured graph)."""
+        perms = self._perm_static if self._perm_static is not None else self._perm_bufs[self._perm_flip ^ 1]
+        srcs = [self.buffer.states.reshape((-1,) + self.buffer.observation_shape),
+                self.buffer.actions.reshape((-1,) + self.buffer.action_shape), self._rec]
+        if self._probe_outs is None:
+            self._probe_outs = [torch.empty((self.minibatch_size,) + tuple(t.shape[1:]), device=self.device) for t in srcs]
+        self.ops.gather(perms[0][:self.minibatch_size], srcs, self._probe_outs, probe=probe)
+
     def _rewind_rng(self, last_epoch_run):
         """Early stop at epoch e: upstream has drawn e+1 shuffles this update, we pre-drew E.
         Re-create the stream position by replaying from the snapshot taken at update start."""
@@ -303,7 +373,7 @@ class ppo:
         for update in range(1, self.num_updates + 1):
             if self.anneal_lr:
                 frac = 1.0 - (update - 1.0) / self.num_updates
-                self.optimizer.param_groups[0]["lr"] = frac * self.learning_rate
+                self.set_lr(frac * self.learning_rate)
             if self._perms is None:
                 self._prefetch_perms()              # overlaps the rollout below
             for step in range(0, self.num_steps):
@@ -335,7 +405,7 @@ class ppo:
         last = sc[-1]                                # logged values are the last minibatch's
         self.last_update = dict(scalars=sc, grad_norms=table[n_steps * ops.N_SCALARS:-2].numpy(),
                                 explained_variance=(np.nan if var_y == 0 else ev))
-        writer.add_scalar("charts/learning_rate", self.optimizer.param_groups[0]["lr"], global_step)
+        writer.add_scalar("charts/learning_rate", self.get_lr(), global_step)
         writer.add_scalar("losses/value_loss", last[ops.S_VL], global_step)
         writer.add_scalar("losses/policy_loss", last[ops.S_PG], global_step)
         writer.add_scalar("losses/entropy", last[ops.S_ENT], global_step)

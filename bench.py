@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--cpu-baseline-updates", type=int, default=2, help="timed CPU-oracle updates (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = usable cores, <=16)")
     ap.add_argument("--no-probe", action="store_true", help="do not time the gather kernel with HIP events")
+    ap.add_argument("--no-graph", action="store_true", help="run the update eagerly instead of as a hipGraph")
     return ap.parse_args()
 
 
@@ -161,11 +162,16 @@ def main():
     data["log_probs"] = agent.buffer.log_probs.cpu()
     agent.seed_all(1)
     probe = EventProbe()
-    agent._probe = None if args.no_probe else probe
+    if args.no_graph:
+        agent.use_graph = False
 
     def one_step():
         returns, advantages = agent.advantages(next_obs, next_done)
         agent.update(returns, advantages)
+        if probe.on and not args.no_probe:
+            # the update replays as a hipGraph, whose kernels cannot carry readable events: time one
+            # extra stand-alone launch of the same gather (same indices, same sources) per step instead
+            agent.probe_gather(probe)
 
     log(f"rank {rank}/{world}: setup done, {args.warmup} warm-up steps")
     for _ in range(args.warmup):
@@ -208,7 +214,9 @@ def main():
         roofline = {"bound": "hbm", "kernel": "k_gather", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "bytes_per_launch": gather_bytes, "avg_launch_us": round(g_ms * 1e3, 2),
-                    "launches_timed": len(probe.pairs)}
+                    "launches_timed": len(probe.pairs),
+                    "how": "HIP-event pairs around one stand-alone launch per step of the update's own gather "
+                           "(the update itself replays as a hipGraph)"}
     out = {"metric": "env-steps/sec through GAE+PPO-update at num_envs=4096,T=128; 1/2/4/8 GPU",
            "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -216,7 +224,8 @@ def main():
            "config": {"workload": f"synthetic continuous obs_dim={Dm} act_dim={A}, num_envs={N}/GPU x {world} GPU, "
                                   f"T={T}, E={args.epochs}, {args.minibatches} minibatches/epoch (M={M}), 2x64 tanh "
                                   "MLP actor+critic, Adam, random-init weights",
-                      "global_num_envs": N * world, "num_steps": T, "parallelism": f"env-shard dp{world}"},
+                      "global_num_envs": N * world, "num_steps": T, "parallelism": f"env-shard dp{world}",
+                      "update_launch": "hipGraph" if agent._graph is not None else "eager"},
            "roofline": roofline}
     if world == 1 and args.cpu_baseline_updates > 0:
         out["cpu_baseline"] = cpu_baseline(args, data, init_sd, args.cpu_baseline_updates)

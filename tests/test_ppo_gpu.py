@@ -138,3 +138,33 @@ def test_split_batch_linear_matches_nn_linear():
     scale = float(b.weight.grad.abs().max())
     assert float((a.weight.grad - b.weight.grad).abs().max()) <= 2e-5 * scale
     assert float((a.bias.grad - b.bias.grad).abs().max()) <= 2e-5 * float(b.bias.grad.abs().max())
+
+
+def test_graph_replay_matches_eager_update():
+    """Same seeds, same buffers: four updates with the update captured as a hipGraph (eager, capture,
+    replay, replay) end in the same weights and scalars as four eager updates."""
+    T, N, Dm, A = 16, 256, 16, 3
+    hp = dict(gym_id="Synthetic-v0", seed=1.0, num_steps=T, gae=True, total_timesteps=T * N * 4, anneal_lr=True,
+              gae_lambda=0.95, num_update_epochs=2, num_envs=N, num_minibatches=4, entropy_coeff=0.01,
+              value_coeff=0.5, clip_coeff=0.2, clip_vloss=True, max_grad_norm=0.5, target_kl=None, norm_adv=True,
+              capture_video=False, hidden_dim=64, continuous=True, learning_rate=3e-4, exp_name="t", num_layers=2,
+              dropout=0.0, gamma=0.99, track=False, log=False, save=False, obs_dim=Dm, act_dim=A)
+    d = synth_rollout(T, N, Dm, A)
+    outs = []
+    for use_graph in (True, False):
+        torch.manual_seed(3)
+        agent = _agent(dict(hp, hip_graph=use_graph))
+        for k in ("states", "actions", "log_probs", "rewards", "terminals", "values"):
+            getattr(agent.buffer, k).copy_(torch.from_numpy(d[k]))
+        agent.seed_all(1)
+        sc = []
+        for u in range(4):
+            agent.set_lr((1 - u / 4) * 3e-4)
+            agent.buffer.rewards.add_(0.01 * u)         # the graph must see in-place buffer changes
+            ret, adv = agent.advantages(torch.from_numpy(d["next_obs"]).cuda(), torch.from_numpy(d["next_done"]).cuda())
+            n = agent.update(ret, adv)
+            sc.append(agent._scalars[:n].clone())
+        assert (agent._graph is not None) == use_graph
+        outs.append((torch.stack(sc), agent.bucket.flat_param.clone()))
+    torch.testing.assert_close(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-7)
