@@ -1,0 +1,71 @@
+"""Plain-CNN encoder / actor / critic of the robot policy with the reference's module layout and
+state-dict keys (src/nets/base_cnns.py:12-84): ``base_encoder.conv.{0,3,6,9,12,14,17}``,
+``base_actor.{conv,mean_linear}``, ``base_critic.{conv,critic.{0,2}}``; xavier init as upstream.
+Stock PyTorch-ROCm (MIOpen convolutions): host code, not a custom kernel."""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+
+def weights_init(m):
+    if isinstance(m, nn.Linear):
+        nn.init.xavier_uniform_(m.weight, gain=1)
+        nn.init.constant_(m.bias, 0)
+    elif isinstance(m, nn.Conv2d):
+        nn.init.xavier_normal_(m.weight.data)
+
+
+class base_encoder(nn.Module):
+    """128x128 -> 64 -> 32 -> 16 -> 8 -> (3x3 valid) 6 -> 3 -> (3x3 valid) 1, channels
+    in-16-32-64-128-256-256-out_dim (src/nets/base_cnns.py:20-54)."""
+
+    def __init__(self, obs_shape=(2, 128, 128), out_dim=1024):
+        super().__init__()
+        mods, c_in = [], obs_shape[0]
+        for c_out in (16, 32, 64, 128):
+            mods += [nn.Conv2d(c_in, c_out, kernel_size=3, padding=1), nn.ReLU(inplace=True), nn.MaxPool2d(2)]
+            c_in = c_out
+        mods += [nn.Conv2d(128, 256, kernel_size=3, padding=1), nn.ReLU(inplace=True),
+                 nn.Conv2d(256, 256, kernel_size=3, padding=0), nn.ReLU(inplace=True), nn.MaxPool2d(2),
+                 nn.Conv2d(256, out_dim, kernel_size=3, padding=0), nn.ReLU(inplace=True), nn.Flatten()]
+        self.conv = nn.Sequential(*mods)
+
+    def forward(self, x):
+        return self.conv(x)
+
+    def forward_split(self, obs, state):
+        """Same result as ``forward(cat([obs, state tiled to a plane], 1))`` without materialising the
+        concatenated (B, C+1, H, W) tensor: convolution is linear in its input channels, so the tiled
+        plane contributes ``state * conv(ones)`` -- one tiny per-call map -- to the first layer."""
+        first = self.conv[0]
+        c = obs.shape[1]
+        y = torch.nn.functional.conv2d(obs, first.weight[:, :c], None, padding=first.padding)
+        ones = torch.ones((1, 1) + tuple(obs.shape[2:]), device=obs.device, dtype=obs.dtype)
+        plane = torch.nn.functional.conv2d(ones, first.weight[:, c:c + 1], None, padding=first.padding)
+        y = y + state.reshape(-1, 1, 1, 1) * plane + first.bias.reshape(1, -1, 1, 1)
+        return self.conv[1:](y)
+
+
+class base_critic(nn.Module):
+    def __init__(self, obs_shape=(2, 128, 128)):
+        super().__init__()
+        self.conv = base_encoder(obs_shape=obs_shape, out_dim=128)
+        self.critic = nn.Sequential(nn.Linear(128, 128), nn.ReLU(inplace=True), nn.Linear(128, 1))
+        self.apply(weights_init)
+
+    def forward(self, obs, state=None):
+        feats = self.conv(obs) if state is None else self.conv.forward_split(obs, state)
+        return self.critic(feats)
+
+
+class base_actor(nn.Module):
+    def __init__(self, obs_shape=(2, 128, 128), action_dim=5):
+        super().__init__()
+        self.conv = base_encoder(obs_shape=obs_shape, out_dim=128)
+        self.mean_linear = nn.Linear(128, action_dim)
+        self.apply(weights_init)
+
+    def forward(self, x, state=None):
+        feats = self.conv(x) if state is None else self.conv.forward_split(x, state)
+        return self.mean_linear(feats)

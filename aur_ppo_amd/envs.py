@@ -137,3 +137,87 @@ def make_vec_env(gym_id, num_envs, continuous, device, params):
         return CartPoleVecEnv(num_envs)
     raise RuntimeError(f"gym is not installed and no built-in environment is named {gym_id!r} "
                        "(built-ins: 'CartPole-v1', 'Synthetic-v0')")
+
+
+class SyntheticArmEnv:
+    """Device-resident stand-in for BulletArm's ``EnvWrapper`` (src/utils/env_wrapper.py:7-59) with its
+    interface: ``reset() -> (states, obs)``, ``step(actions, auto_reset=False) -> (states, obs, rewards,
+    dones)``, ``getNextAction() -> plan (N, 5)``.  Observations are (N, 1, H, W) heightmap-like images,
+    ``states`` the gripper open/closed flag.  Used when bulletarm is not installed (it is not part of
+    this image) and for the synthetic image-observation configs of BASELINE.json."""
+    device_native = True
+
+    def __init__(self, num_envs, device, obs_size=128, seed=4321, p_done=0.02, p_reward=0.05):
+        self.num_envs, self.device, self.obs_size = num_envs, torch.device(device), obs_size
+        self.p_done, self.p_reward = p_done, p_reward
+        self.gen = torch.Generator(device=self.device)
+        self.gen.manual_seed(seed)
+
+    def _draw(self):
+        n, dev, g = self.num_envs, self.device, self.gen
+        states = (torch.rand(n, device=dev, generator=g) < 0.5).float()
+        obs = torch.rand((n, 1, self.obs_size, self.obs_size), device=dev, generator=g)
+        return states, obs
+
+    def reset(self):
+        return self._draw()
+
+    def getNextAction(self):
+        n, dev, g = self.num_envs, self.device, self.gen
+        plan = torch.randn((n, 5), device=dev, generator=g) * torch.tensor([0.5, 0.02, 0.02, 0.02, 0.4], device=dev)
+        plan[:, 0] = (plan[:, 0] > 0).float()
+        return plan
+
+    def step(self, actions, auto_reset=False):
+        n, dev, g = self.num_envs, self.device, self.gen
+        rewards = (torch.rand(n, device=dev, generator=g) < self.p_reward).float()
+        dones = (torch.rand(n, device=dev, generator=g) < self.p_done).float()
+        states, obs = self._draw()
+        return states, obs, rewards, dones
+
+    def close(self):
+        pass
+
+
+def make_arm_envs(gym_id, num_envs, device, params, seed_offset=0):
+    """bulletarm's env_factory when importable (same config as src/robot_ppo.py:113-135), else the
+    synthetic stand-in."""
+    if not str(gym_id).lower().startswith("synthetic"):
+        try:
+            from bulletarm import env_factory
+        except ImportError:
+            env_factory = None
+        if env_factory is not None:
+            env_config = {"workspace": np.array([[0.25, 0.65], [-0.2, 0.2], [0.01, 0.25]]), "max_steps": 100,
+                          "obs_size": 128, "fast_mode": True, "action_sequence": "pxyzr",
+                          "render": params.get("render", False), "num_objects": 2, "random_orientation": True,
+                          "robot": "kuka", "workspace_check": "point", "object_scale_range": (1, 1),
+                          "hard_reset_freq": 100, "physics_mode": "fast", "view_type": "camera_center_xyz",
+                          "obs_type": "pixel", "view_scale": 1.5, "transparent_bin": True}
+            planner_config = {"random_orientation": True, "dpos": 0.02, "drot": 0.19634954084936207}
+            return _BulletArmWrapper(env_factory.createEnvs(num_envs, gym_id, env_config, planner_config))
+    return SyntheticArmEnv(num_envs, device, obs_size=int(params.get("obs_size", 128)),
+                           seed=int(params.get("env_seed", 4321)) + seed_offset)
+
+
+class _BulletArmWrapper:
+    """``EnvWrapper`` over a real bulletarm runner: numpy in, float tensors out."""
+    device_native = False
+
+    def __init__(self, envs):
+        self.envs = envs
+
+    def reset(self):
+        states, _in_hands, obs = self.envs.reset()
+        return torch.tensor(states).float(), torch.tensor(obs).float()
+
+    def getNextAction(self):
+        return torch.tensor(self.envs.getNextAction()).float()
+
+    def step(self, actions, auto_reset=False):
+        (states, _in_hands, obs), rewards, dones = self.envs.step(actions.cpu().numpy(), auto_reset)
+        return (torch.tensor(states).float(), torch.tensor(obs).float(), torch.tensor(rewards).float(),
+                torch.tensor(dones).float())
+
+    def close(self):
+        self.envs.close()

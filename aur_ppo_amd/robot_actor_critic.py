@@ -1,0 +1,88 @@
+"""``robot_actor_critic`` with the reference's API (src/models/robot_actor_critic.py:19-157):
+``robot_actor_critic(device, equivariant, dx=.02, dy=.02, dz=.02, dr=pi/8, n_a=5, tau=.001)``,
+``.evaluate(state, obs, action=None) -> (actions, unscaled_actions, log_prob (B,), entropy (B,), value)``,
+``.value(state, obs)``, ``.decodeActions(*cols)``, ``.getActionFromPlan(plan)``, ``.test_action``.
+
+The equivariant branch wraps e2cnn 0.2.3 upstream (src/nets/equiv.py); e2cnn is neither vendored
+nor installed, and no reference test pins it, so it is not built here (parity unpinned -- DESIGN.md)."""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+from .base_cnns import base_actor, base_critic, base_encoder, weights_init
+
+_HALF_LOG_2PI = 0.5 * math.log(2.0 * math.pi)
+
+
+class robot_actor_critic(nn.Module):
+    def __init__(self, device, equivariant: bool, dx=0.02, dy=0.02, dz=0.02, dr=np.pi / 8, n_a=5, tau=0.001) -> None:
+        super().__init__()
+        self.p_range = torch.tensor([0, 1])
+        self.dtheta_range = torch.tensor([-dr, dr])
+        self.dx_range = torch.tensor([-dx, dx])
+        self.dy_range = torch.tensor([-dy, dy])
+        self.dz_range = torch.tensor([-dz, dz])
+        self.n_a = n_a
+        self.device = device
+        self.equivariant = equivariant
+        if equivariant:
+            raise NotImplementedError(
+                "equivariant=True needs e2cnn's C4 steerable convolutions (src/nets/equiv.py), a third-party "
+                "dependency that is not available offline and whose arithmetic no reference test pins")
+        self.network = base_encoder(obs_shape=(2, 128, 128), out_dim=128)   # unused upstream too; kept for state dicts
+        self.actor = base_actor()
+        self.actor.apply(weights_init)
+        self.actor_logstd = nn.Parameter(torch.zeros(1, 5))
+        self.critic = base_critic()
+        self.critic.apply(weights_init)
+
+    def forward(self, act):
+        pass
+
+    def value(self, state, obs):
+        # upstream tiles the gripper state to a plane and concatenates it (:58-59); folded into conv 1 here
+        return self.critic(obs.to(self.device), state.to(self.device))
+
+    @staticmethod
+    def _scale(u, rng):
+        return 0.5 * (u + 1) * (rng[1] - rng[0]) + rng[0]
+
+    def decodeActions(self, *args):
+        cols = [args[0], args[1], args[2], args[3]]
+        rngs = [self.p_range, self.dx_range, self.dy_range, self.dz_range]
+        if self.n_a == 5:
+            cols.append(args[4])
+            rngs.append(self.dtheta_range)
+        actions = torch.stack([self._scale(u, r.to(u.device)) for u, r in zip(cols, rngs)], dim=1)
+        return torch.stack(cols, dim=1), actions
+
+    def getActionFromPlan(self, plan):
+        def unscale(a, rng):
+            return 2 * (a - rng[0]) / (rng[1] - rng[0]) - 1
+        rngs = [self.p_range, self.dx_range, self.dy_range, self.dz_range] + ([self.dtheta_range] if self.n_a == 5 else [])
+        cols = []
+        for i, r in enumerate(rngs):
+            r = r.to(plan.device)
+            cols.append(unscale(plan[:, i].clamp(r[0], r[1]), r))
+        return self.decodeActions(*cols)
+
+    def evaluate(self, state, obs, action=None):
+        state, obs = state.to(self.device), obs.to(self.device)
+        mean = self.actor(obs, state)
+        logstd = self.actor_logstd.expand_as(mean)
+        std = torch.exp(logstd)
+        if action is None:
+            action = mean + std * torch.randn_like(mean)            # == Normal(mean, std).rsample()
+        z = action - mean
+        log_prob = (-(z * z) / (2 * std * std) - logstd - _HALF_LOG_2PI).sum(1)
+        entropy = (0.5 + _HALF_LOG_2PI + logstd).sum(1)
+        unscaled_actions, actions = self.decodeActions(*[action[:, i] for i in range(self.n_a)])
+        return actions, unscaled_actions, log_prob, entropy, self.critic(obs, state)
+
+    def test_action(self, state, obs):
+        mean = torch.tanh(self.actor(obs.to(self.device), state.to(self.device)))
+        return self.decodeActions(*[mean[:, i] for i in range(self.n_a)])

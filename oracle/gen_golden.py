@@ -503,6 +503,38 @@ def gen_evaluate(ref_ac):
     print("evaluate.npz:", names)
 
 
+# ----------------------------------------------------------------------------- 6. robot_actor_critic
+def gen_robot_eval():
+    """Non-equivariant robot policy (src/models/robot_actor_critic.py): seeded construction (xavier init
+    draws), evaluate / value / decodeActions / getActionFromPlan outputs.  The weights (15 MB) are not
+    stored: the test rebuilds them from the same seed and checks their digest."""
+    from src.models.robot_actor_critic import robot_actor_critic as ref_rac
+    out = {}
+    torch.manual_seed(1)
+    net = ref_rac(torch.device("cpu"), False)
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        net.actor_logstd.copy_(0.2 * torch.randn(1, 5, generator=g))
+    state = (torch.rand(4, generator=g) < 0.5).float()
+    obs = torch.rand(4, 1, 128, 128, generator=g)
+    act = 0.5 * torch.randn(4, 5, generator=g)
+    plan = torch.stack([torch.rand(4, generator=g), 0.05 * torch.randn(4, generator=g), 0.05 * torch.randn(4, generator=g),
+                        0.05 * torch.randn(4, generator=g), torch.randn(4, generator=g)], 1)
+    with torch.no_grad():
+        actions, unscaled, logp, ent, val = net.evaluate(state, obs, act)
+        v2 = net.value(state, obs)
+        u_plan, a_plan = net.getActionFromPlan(plan)
+    out["sd_sha"] = np.frombuffer(hashlib.sha256(b"".join(v.numpy().tobytes() for v in net.state_dict().values())).digest(),
+                                  dtype=np.uint8)
+    out["sd_keys"] = np.array(list(net.state_dict().keys()))
+    out["logstd"] = net.actor_logstd.detach().numpy().copy()
+    for k, v in (("state", state), ("obs", obs), ("act", act), ("plan", plan), ("actions", actions), ("unscaled", unscaled),
+                 ("logp", logp), ("ent", ent), ("val", val), ("value_fn", v2), ("u_plan", u_plan), ("a_plan", a_plan)):
+        out[k] = v.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "robot_eval.npz"), **out)
+    print("robot_eval.npz written")
+
+
 def main():
     assert os.path.isdir(REF), f"reference not present at {REF} (fixtures are generated in the build container only)"
     os.makedirs(OUT, exist_ok=True)
@@ -514,6 +546,7 @@ def main():
     gen_loss(ref_ppo)
     gen_trace(ref_ppo)
     gen_evaluate(ref_ac)
+    gen_robot_eval()
 
 
 if __name__ == "__main__":

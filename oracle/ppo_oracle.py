@@ -434,3 +434,49 @@ def reference_update(policy, optimizer, buf, next_obs, next_done, hp, rng, colle
             break
     return {"returns": returns, "advantages": advantages,
             "scalars": np.array(out_scalars, dtype=np.float64), "perms": perms}
+
+
+def reference_robot_update(policy, optimizer, flat, hp, rng, minibatch_size):
+    """``robot_ppo.update`` (src/robot_ppo.py:329-408) on CPU torch tensors with the intended (T,N)
+    log-prob semantics (upstream's (T,N,A) buffer is ill-defined).  ``flat`` is the tuple of
+    ``torch_buffer.flatten``.  Differences from ``ppo``: 5-tuple ``evaluate(state, obs, action)``,
+    un-clipped value loss regresses to the returns (:390), ``clip_grad_norm_`` over the actor's
+    parameters only (:401), the reported value loss is pre-multiplied by value_coeff (:392).  The
+    expert MSE term (:397) is between two buffer tensors and contributes no gradient; omitted."""
+    torch = _torch()
+    nn = torch.nn
+    (b_states, b_obs, b_logprobs, b_actions, b_adv, b_ret, b_val, _b_true) = flat
+    B = b_states.shape[0]
+    clip = hp["clip_coeff"]
+    b_inds = np.arange(B)
+    rows = []
+    for _ep in range(hp["num_update_epochs"]):
+        rng.shuffle(b_inds)
+        for start in range(0, B, minibatch_size):
+            mbi = b_inds[start:start + minibatch_size]
+            _, _, newlogprob, entropy, newvalue = policy.evaluate(b_states[mbi], b_obs[mbi], b_actions[mbi])
+            log_ratio = newlogprob - b_logprobs[mbi]
+            ratio = log_ratio.exp()
+            with torch.no_grad():
+                old_kl = (-log_ratio).mean()
+                kl = ((ratio - 1) - log_ratio).mean()
+                clipfrac = ((ratio - 1.0).abs() > clip).float().mean()
+            mb_adv = b_adv[mbi]
+            if hp.get("norm_adv", True):
+                mb_adv = (mb_adv - mb_adv.mean()) / (mb_adv.std() + 1e-8)
+            pg = torch.max(-mb_adv * ratio, -mb_adv * torch.clamp(ratio, 1 - clip, 1 + clip)).mean()
+            newvalue = newvalue.view(-1)
+            if hp.get("clip_vloss", True):
+                v_un = (newvalue - b_ret[mbi]) ** 2
+                v_cl = (b_val[mbi] + torch.clamp(newvalue - b_val[mbi], -clip, clip) - b_ret[mbi]) ** 2
+                vl = 0.5 * torch.max(v_un, v_cl).mean()
+            else:
+                vl = 0.5 * ((newvalue - b_ret[mbi]) ** 2).mean()
+            ent = entropy.mean()
+            loss = pg - hp["entropy_coeff"] * ent + vl * hp["value_coeff"]
+            optimizer.zero_grad()
+            loss.backward()
+            nn.utils.clip_grad_norm_(policy.actor.parameters(), hp["max_grad_norm"])
+            optimizer.step()
+            rows.append([x.detach().item() for x in (loss, pg, vl, ent, old_kl, kl, clipfrac)])
+    return np.array(rows, dtype=np.float64)

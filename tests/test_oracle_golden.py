@@ -231,3 +231,26 @@ def test_c_oracle_matches_golden_and_numpy_oracle():
         np.testing.assert_allclose(g0, zl[f"{name}/g_newlogp"], rtol=1e-5, atol=1e-8, err_msg=name)
         np.testing.assert_allclose(g1, zl[f"{name}/g_newv"], rtol=1e-5, atol=1e-9, err_msg=name)
         np.testing.assert_allclose(g2, zl[f"{name}/g_entropy"], rtol=1e-6, err_msg=name)
+
+
+# ------------------------------------------------------------------ robot policy (src/models/robot_actor_critic.py)
+def test_robot_actor_critic_matches_reference_construction_and_outputs():
+    from aur_ppo_amd.robot_actor_critic import robot_actor_critic
+    torch.set_num_threads(1)
+    z = load("robot_eval.npz")
+    torch.manual_seed(1)
+    net = robot_actor_critic(torch.device("cpu"), False)
+    assert list(net.state_dict().keys()) == [str(k) for k in z["sd_keys"]]
+    with torch.no_grad():
+        net.actor_logstd.copy_(torch.from_numpy(z["logstd"]))
+    sha = np.frombuffer(hashlib.sha256(b"".join(v.numpy().tobytes() for v in net.state_dict().values())).digest(),
+                        dtype=np.uint8)
+    assert (sha == z["sd_sha"]).all(), "seeded construction must draw the same init stream as upstream"
+    state, obs, act = (torch.from_numpy(z[k]) for k in ("state", "obs", "act"))
+    with torch.no_grad():
+        actions, unscaled, logp, ent, val = net.evaluate(state, obs, act)
+        v2 = net.value(state, obs)
+        u_plan, a_plan = net.getActionFromPlan(torch.from_numpy(z["plan"]))
+    for got, key in ((actions, "actions"), (unscaled, "unscaled"), (logp, "logp"), (ent, "ent"), (val, "val"),
+                     (v2, "value_fn"), (u_plan, "u_plan"), (a_plan, "a_plan")):
+        np.testing.assert_allclose(got.numpy(), z[key], rtol=2e-5, atol=2e-6, err_msg=key)

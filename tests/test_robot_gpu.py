@@ -1,0 +1,66 @@
+"""GPU: robot_ppo (image observations, CNN policy) on the HIP path vs the CPU restatement."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_robot_update_matches_cpu_restatement():
+    from aur_ppo_amd.robot_actor_critic import robot_actor_critic
+    from aur_ppo_amd.robot_ppo import robot_ppo
+    from aur_ppo_amd.robot_run import build_parser, params_from_args
+    from oracle import ppo_oracle as O
+    p = params_from_args(build_parser().parse_args([]))
+    p.update(gym_id="Synthetic-arm", num_envs=4, num_steps=8, total_timesteps=64, num_update_epochs=2, num_minibatches=2,
+             do_pretraining=False, log=False, clip_vloss=True, entropy_coeff=0.01)
+    torch.manual_seed(2)
+    agent = robot_ppo(p)
+    assert agent.device.type == "cuda"
+    cpu = robot_actor_critic(torch.device("cpu"), False)
+    cpu.load_state_dict({k: v.cpu() for k, v in agent.policy.state_dict().items()})
+    g = torch.Generator().manual_seed(9)
+    T, N = 8, 4
+    buf = dict(states=(torch.rand(T, N, generator=g) < 0.5).float(), observations=torch.rand(T, N, 1, 128, 128, generator=g),
+               actions=0.3 * torch.randn(T, N, 5, generator=g), true_actions=torch.zeros(T, N, 5),
+               rewards=(torch.rand(T, N, generator=g) < 0.3).float(), terminals=(torch.rand(T, N, generator=g) < 0.1).float())
+    with torch.no_grad():
+        _, _, lp, _, v = cpu.evaluate(buf["states"].view(-1), buf["observations"].view(-1, 1, 128, 128), buf["actions"].view(-1, 5))
+    buf["log_probs"] = (lp.view(T, N) + 0.05 * torch.randn(T, N, generator=g))
+    buf["values"] = v.view(T, N).clone()
+    for k, t in buf.items():
+        getattr(agent.buffer, k).copy_(t)
+    next_state, next_obs = (torch.rand(N, generator=g) < 0.5).float(), torch.rand(N, 1, 128, 128, generator=g)
+    next_done = torch.zeros(N)
+    agent.seed_all(1)
+    ret, adv = agent.advantages(next_state.cuda(), next_obs.cuda(), next_done.cuda(), agent.buffer, T)
+    # skip-last GAE as upstream (F4): checked against the oracle given the CPU bootstrap value
+    with torch.no_grad():
+        nv = cpu.value(next_state, next_obs).flatten()
+    ret_o, adv_o = O.gae(buf["rewards"].numpy(), buf["values"].numpy(), buf["terminals"].numpy(), nv.numpy(),
+                         next_done.numpy(), 0.99, 0.95, O.GAE_MODE_SKIP_LAST)
+    np.testing.assert_allclose(adv.cpu().numpy(), adv_o, atol=1e-5)
+    assert float(adv[-1].abs().max()) == 0.0
+    out = agent.update(agent.buffer.flatten(ret, adv), 2, agent.batch_size, agent.minibatch_size, [])
+    flat_cpu = (buf["states"].view(-1), buf["observations"].view(-1, 1, 128, 128), buf["log_probs"].reshape(-1),
+                buf["actions"].view(-1, 5), torch.from_numpy(adv_o).reshape(-1), torch.from_numpy(ret_o).reshape(-1),
+                buf["values"].reshape(-1), buf["true_actions"].view(-1, 5))
+    opt = torch.optim.Adam(cpu.parameters(), lr=p["learning_rate"], eps=1e-5)
+    rows = O.reference_robot_update(cpu, opt, flat_cpu, p, np.random.RandomState(1), agent.minibatch_size)
+    got = agent._last_scalars
+    assert got.shape[0] == rows.shape[0] == 4
+    np.testing.assert_allclose(got[:, :6], rows[:, :6], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(float(out[1]), rows[-1, 2] * p["value_coeff"], rtol=2e-4, atol=2e-6)
+    for (k, a), (_, b) in zip(agent.policy.state_dict().items(), cpu.state_dict().items()):
+        np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=1e-3, atol=3e-5, err_msg=k)
+
+
+def test_robot_train_runs_on_gpu():
+    from aur_ppo_amd.robot_ppo import robot_ppo
+    from aur_ppo_amd.robot_run import build_parser, params_from_args
+    p = params_from_args(build_parser().parse_args([]))
+    p.update(gym_id="Synthetic-arm", num_envs=8, num_steps=16, total_timesteps=2 * 128, num_update_epochs=2,
+             num_minibatches=4, pretrain_steps=4, pretrain_batch_size=2, do_pretraining=True, log=False)
+    a = robot_ppo(p)
+    a.train()
+    assert np.isfinite(a._last_scalars).all() and a._last_scalars.shape == (8, 9)
