@@ -94,3 +94,11 @@ def grad_norm_clip_(flat_grads, max_norm, out_norm=None):
         out_norm.fill_(norm)
         return out_norm
     return torch.tensor([norm])
+
+
+def loss_fwd_bwd(newlogp, oldlogp, adv, newv, oldv, ret, entropy, clip, ent_coef, vf_coef, norm_adv=True,
+                 vloss_mode=VLOSS_CLIPPED, out_scalars=None):
+    n = lambda t: t.detach().reshape(-1).numpy()
+    sc, g_lp, g_v, g_e = CO.ppo_loss(n(newlogp), n(oldlogp), n(adv), n(newv), n(oldv), n(ret), n(entropy), clip, ent_coef,
+                                     vf_coef, norm_adv, vloss_mode)
+    return torch.from_numpy(sc), torch.from_numpy(g_lp), torch.from_numpy(g_v), torch.from_numpy(g_e)
