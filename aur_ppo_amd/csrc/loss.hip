@@ -11,7 +11,7 @@
 // which is why the combine steps are kernels and not "last block done" epilogues.
 // Reductions are wave-shuffle -> LDS -> fixed-order, so results are run-to-run deterministic.
 // HBM traffic: 28 B read + 8 B written per sample (+4 B for the statistics pass, L2-resident).
-#include "common.h"
+#include "ppo_math.h"
 
 namespace {
 
@@ -44,10 +44,8 @@ __global__ __launch_bounds__(kThreads) void k_adv_stats(const float* __restrict_
 }
 
 struct LossParams {
-    int M;
+    PpoHyper h;
     int n_stat_blocks;
-    float clip, lo, hi, ent_coef, vf_coef;
-    int norm_adv, vloss_mode;
 };
 
 // PACKED: oldlogp points at a (M,4) record {old_logp, adv, ret, old_v}; adv/oldv/ret are ignored
@@ -71,8 +69,8 @@ __global__ __launch_bounds__(kThreads) void k_loss(const float* __restrict__ new
         const double ts = block_sum<kNW>(s, sc[0]);
         const double tq = block_sum<kNW>(q, sc[1]);
         if (threadIdx.x == 0) {
-            const double m = ts / (double)p.M;
-            double var = (tq - ts * m) / (double)(p.M - 1);  // M == 1 -> 0/0 = NaN, like torch.std
+            const double m = ts / (double)p.h.M;
+            double var = (tq - ts * m) / (double)(p.h.M - 1);  // M == 1 -> 0/0 = NaN, like torch.std
             if (var < 0.0) var = 0.0;
             s_mean = (float)m;
             s_std = (float)sqrt(var);
@@ -81,10 +79,10 @@ __global__ __launch_bounds__(kThreads) void k_loss(const float* __restrict__ new
     }
     const float mean = s_mean;
     const float denom = s_std + 1e-8f;
-    const float invM = 1.0f / (float)p.M;
-    const float g_ent = -p.ent_coef * invM;
+    const float invM = 1.0f / (float)p.h.M;
+    const float g_ent = -p.h.ent_coef * invM;
     double a_pg = 0.0, a_vl = 0.0, a_ent = 0.0, a_okl = 0.0, a_kl = 0.0, a_cf = 0.0;
-    for (int i = blockIdx.x * kThreads + threadIdx.x; i < p.M; i += gridDim.x * kThreads) {
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < p.h.M; i += gridDim.x * kThreads) {
         float ol_, a_raw, vo, R;
         if (PACKED) {
             const float4 r4 = reinterpret_cast<const float4*>(oldlogp)[i];
@@ -98,41 +96,14 @@ __global__ __launch_bounds__(kThreads) void k_loss(const float* __restrict__ new
             R = ret[i];
             vo = oldv[i];
         }
-        const float lr = newlogp[i] - ol_;
-        const float ratio = expf(lr);
-        const float an = p.norm_adv ? (a_raw - mean) / denom : a_raw;
-        a_okl += (double)(-lr);
-        a_kl += (double)((ratio - 1.0f) - lr);
-        a_cf += (fabsf(ratio - 1.0f) > p.clip) ? 1.0 : 0.0;
-        // policy term: max(-A*ratio, -A*clamp(ratio, lo, hi))
-        const float rc = fminf(fmaxf(ratio, p.lo), p.hi);
-        const float l1 = -an * ratio;
-        const float l2 = -an * rc;
-        a_pg += (double)fmaxf(l1, l2);
-        const float w1 = l1 > l2 ? 1.0f : (l1 == l2 ? 0.5f : 0.0f);
-        const float inr = (ratio >= p.lo && ratio <= p.hi) ? 1.0f : 0.0f;
-        const float dpg = (w1 * (-an) + (1.0f - w1) * (-an) * inr) * invM;
-        g_newlogp[i] = dpg * ratio;
-        // value term
-        const float v = newv[i];
-        float dvl;
-        if (p.vloss_mode == AURPPO_VLOSS_CLIPPED) {
-            const float du = v - R;
-            const float vu = du * du;
-            const float dv = v - vo;
-            const float dcl = fminf(fmaxf(dv, -p.clip), p.clip);
-            const float dc = (vo + dcl) - R;
-            const float vc = dc * dc;
-            a_vl += (double)fmaxf(vu, vc);
-            const float u1 = vu > vc ? 1.0f : (vu == vc ? 0.5f : 0.0f);
-            const float inv = (dv >= -p.clip && dv <= p.clip) ? 1.0f : 0.0f;
-            dvl = (u1 * (2.0f * du) + (1.0f - u1) * (2.0f * dc) * inv) * (0.5f * invM);
-        } else {
-            const float du = v - (p.vloss_mode == AURPPO_VLOSS_RETURNS ? R : vo);
-            a_vl += (double)(du * du);
-            dvl = (2.0f * du) * (0.5f * invM);
-        }
-        g_newv[i] = dvl * p.vf_coef;
+        const PpoSample t = ppo_sample(newlogp[i], ol_, a_raw, newv[i], vo, R, mean, denom, invM, p.h);
+        a_okl += (double)t.okl;
+        a_kl += (double)t.kl;
+        a_cf += (double)t.cf;
+        a_pg += (double)t.pg;
+        a_vl += (double)t.vl;
+        g_newlogp[i] = t.g_logp;
+        g_newv[i] = t.g_v;
         a_ent += (double)entropy[i];
         g_entropy[i] = g_ent;
     }
@@ -165,7 +136,7 @@ __global__ __launch_bounds__(kThreads) void k_loss_final(const LossWs* __restric
 #pragma unroll
     for (int k = 0; k < 6; ++k) r[k] = block_sum<kNW>(a[k], sc[k]);
     if (threadIdx.x == 0) {
-        const double M = (double)p.M;
+        const double M = (double)p.h.M;
         const float pg = (float)(r[0] / M);
         const float vl = 0.5f * (float)(r[1] / M);
         const float ent = (float)(r[2] / M);
@@ -175,7 +146,7 @@ __global__ __launch_bounds__(kThreads) void k_loss_final(const LossWs* __restric
         out[AURPPO_S_OLD_KL] = (float)(r[3] / M);
         out[AURPPO_S_KL] = (float)(r[4] / M);
         out[AURPPO_S_CLIPFRAC] = (float)(r[5] / M);
-        out[AURPPO_S_LOSS] = (pg - p.ent_coef * ent) + vl * p.vf_coef;
+        out[AURPPO_S_LOSS] = (pg - p.h.ent_coef * ent) + vl * p.h.vf_coef;
         out[AURPPO_S_ADV_MEAN] = (float)ws->stats[kMaxBlocks - 1][0];
         out[AURPPO_S_ADV_STD] = (float)ws->stats[kMaxBlocks - 1][1];
     }
@@ -204,14 +175,7 @@ static int loss_launch(bool packed, const float* newlogp, const float* oldlogp, 
     LossWs* ws = reinterpret_cast<LossWs*>(workspace);
     hipStream_t s = (hipStream_t)stream;
     LossParams p;
-    p.M = M;
-    p.clip = (float)clip;
-    p.lo = (float)(1.0 - clip);  // Python forms 1-eps / 1+eps in fp64; torch rounds them to fp32
-    p.hi = (float)(1.0 + clip);
-    p.ent_coef = (float)ent_coef;
-    p.vf_coef = (float)vf_coef;
-    p.norm_adv = norm_adv ? 1 : 0;
-    p.vloss_mode = vloss_mode;
+    p.h = make_hyper(M, clip, ent_coef, vf_coef, norm_adv, vloss_mode);
     // 4 samples per lane per pass; the last stats slot is reserved for the mean/std stash
     int blocks = (M + kThreads * 4 - 1) / (kThreads * 4);
     if (blocks > kMaxBlocks - 1) blocks = kMaxBlocks - 1;

@@ -269,6 +269,72 @@ def ppo_loss(newlogp, newv, entropy, oldlogp, adv, oldv, ret, clip, ent_coef, vf
                            vloss_mode, out_scalars)
 
 
+# ------------------------------------------------------------------ K7
+MLP_HIDDEN, MLP_MAX_D, MLP_MAX_A = 64, 64, 16
+
+
+def mlp_layout(policy, bucket):
+    """Float offsets {w1,b1,w2,b2,w3,b3} x {actor, critic} + actor_logstd of ``policy`` (an
+    ``actor_critic`` with two hidden layers) inside ``bucket``'s flat buffers, or None if the policy
+    does not have the shape K7 is built for."""
+    if not getattr(policy, "continuous", False) or getattr(policy, "num_layers", None) != 2:
+        return None
+    if getattr(policy, "hidden_dim", None) != MLP_HIDDEN:
+        return None
+    off, pos = {}, 0
+    for p in bucket.params:
+        off[id(p)] = pos
+        pos += p.numel()
+    try:
+        seq = []
+        for net in (policy.actor.net, policy.critic.net):
+            for li in (0, 2, 4):
+                seq += [off[id(net[li].weight)], off[id(net[li].bias)]]
+        seq.append(off[id(policy.actor_logstd)])
+    except (KeyError, AttributeError, IndexError):
+        return None
+    D = policy.actor.net[0].weight.shape[1]
+    A = policy.actor.net[4].weight.shape[0]
+    if D % 2 or D > MLP_MAX_D or A > MLP_MAX_A or policy.critic.net[4].weight.shape[0] != 1:
+        return None
+    return dict(offsets=seq, n_params=pos, D=D, A=A)
+
+
+def mlp_step_flops(layout, M):
+    """Algorithmic FLOPs of one K7 launch (un-padded): forward of both nets, weight gradients of every
+    layer, input gradients of layers 2 and 3 (layer 1 needs none)."""
+    D, A, Hd = layout["D"], layout["A"], MLP_HIDDEN
+    fwd = (D * Hd + Hd * Hd + Hd * A) + (D * Hd + Hd * Hd + Hd)
+    bwd = fwd + (Hd * Hd + Hd * A) + (Hd * Hd + Hd)
+    return 2 * (fwd + bwd) * M
+
+
+def mlp_ppo_step(obs, actions, rec, idx, flat_param, layout, flat_grad, clip, ent_coef, vf_coef, norm_adv=True,
+                 vloss_mode=VLOSS_CLIPPED, out_scalars=None, events=None):
+    """K7: gather + evaluate + loss + backward for one minibatch of the MLP actor-critic; overwrites
+    ``flat_grad[:n_params]`` and returns the 9 loss scalars.  ``events``: optional pair of
+    ``torch.cuda.Event(enable_timing=True)`` recorded right around the main kernel (bench.py)."""
+    lib = _lib_or_raise()
+    M, D, A, n = idx.numel(), layout["D"], layout["A"], layout["n_params"]
+    if obs.shape[-1] != D or actions.numel() != obs.shape[0] * A or rec.numel() != obs.shape[0] * 4:
+        raise ValueError("mlp_ppo_step: buffer shapes do not match the policy")
+    if out_scalars is None:
+        out_scalars = torch.empty(N_SCALARS, dtype=torch.float32, device=obs.device)
+    ws = _workspace("mlp", lib.aurppo_mlp_workspace_bytes(n), obs.device)
+    lay = (C.c_int * 13)(*layout["offsets"])
+    args = (_ptr(obs), _ptr(actions), _ptr(rec), _ptr(idx, torch.int32), M, D, A, MLP_HIDDEN, _ptr(flat_param), lay, n,
+            _ptr(flat_grad), float(clip), float(ent_coef), float(vf_coef), int(bool(norm_adv)), int(vloss_mode),
+            _ptr(out_scalars), C.c_void_p(ws.data_ptr()), _stream())
+    if events is None:
+        _check(lib.aurppo_mlp_ppo_step_f32(*args), "aurppo_mlp_ppo_step_f32")
+    else:
+        for ev in events:          # materialise the hipEvent handles (torch creates them lazily on record())
+            ev.record()
+        _check(lib.aurppo_mlp_ppo_step_ev_f32(*args, C.c_void_p(events[0].cuda_event), C.c_void_p(events[1].cuda_event)),
+               "aurppo_mlp_ppo_step_ev_f32")
+    return out_scalars
+
+
 # ------------------------------------------------------------------ K6
 def grad_norm_clip_(flat_grads, max_norm, out_norm=None):
     """In-place ``clip_grad_norm_`` over one flat gradient bucket (src/ppo.py:268).  Returns the
@@ -280,4 +346,22 @@ def grad_norm_clip_(flat_grads, max_norm, out_norm=None):
     ws = _workspace("clip", lib.aurppo_clip_workspace_bytes(n), flat_grads.device)
     _check(lib.aurppo_grad_norm_clip_f32(_ptr(flat_grads), n, float(max_norm), _ptr(out_norm),
                                          C.c_void_p(ws.data_ptr()), _stream()), "aurppo_grad_norm_clip_f32")
+    return out_norm
+
+
+def clip_adam_(flat_param, flat_grad, exp_avg, exp_avg_sq, lr_dev, step_dev, max_norm, clip_n=None, betas=(0.9, 0.999),
+               eps=1e-5, out_norm=None):
+    """K6b: ``clip_grad_norm_`` over the first ``clip_n`` elements + ``Adam.step`` over the whole flat
+    bucket, two launches.  ``lr_dev`` / ``step_dev`` are 1-element device tensors (step is incremented)."""
+    lib = _lib_or_raise()
+    n = flat_param.numel()
+    if clip_n is None:
+        clip_n = n
+    if out_norm is None:
+        out_norm = torch.empty(1, dtype=torch.float32, device=flat_param.device)
+    ws = _workspace("clip", lib.aurppo_clip_workspace_bytes(n), flat_param.device)
+    _check(lib.aurppo_clip_adam_f32(_ptr(flat_param), _ptr(flat_grad), _ptr(exp_avg), _ptr(exp_avg_sq), n, int(clip_n),
+                                    float(max_norm), _ptr(lr_dev), _ptr(step_dev), float(betas[0]), float(betas[1]),
+                                    float(eps), _ptr(out_norm), C.c_void_p(ws.data_ptr()), _stream()),
+           "aurppo_clip_adam_f32")
     return out_norm

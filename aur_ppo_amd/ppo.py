@@ -118,6 +118,7 @@ class ppo:
         else:
             self._lr_tensor = None
             self.optimizer = torch.optim.Adam(self.policy.parameters(), lr=self.learning_rate, eps=1e-5)
+        self._adam_setup()
         self.total_returns = []
         self.total_episode_lengths = []
         self.x_indices = []
@@ -133,6 +134,11 @@ class ppo:
         self._norms = torch.zeros(n_steps, device=self.device)
         self.last_update = None
         self._probe_outs = None
+        self._probe_mlp_outs = None
+        # K7: fused gather + forward + loss + backward for the MLP actor-critic (None: per-op path)
+        self._mlp = None
+        if params.get("fused_mlp", True) and self.device.type == "cuda" and hasattr(ops, "mlp_layout"):
+            self._mlp = ops.mlp_layout(self.policy, self.bucket)
         self._graph = None         # captured update (hipGraph), see update()
         self._graph_state = 0      # 0: next update runs eagerly (warm-up), 1: capture, 2: replay
         self._perm_static = None
@@ -140,6 +146,34 @@ class ppo:
         self._rec = None           # (B,4) per-sample record written by K1
         self._rec_of = None
         self._probe = None         # bench.py hangs HIP-event pairs around the gather launches here
+
+    def _adam_setup(self):
+        """Flat Adam state for K6b (clip + Adam fused).  The torch optimizer object stays -- upstream code
+        reads ``optimizer.param_groups`` / ``state_dict()`` -- with its per-parameter state entries aliased to
+        views of the flat moment buffers and a shared device step counter."""
+        self._fused_adam = self.device.type == "cuda" and hasattr(self.ops, "clip_adam_")
+        if not self._fused_adam:
+            return
+        fp = self.bucket.flat_param
+        self._adam_m, self._adam_v = torch.zeros_like(fp), torch.zeros_like(fp)
+        self._adam_t = torch.zeros(1, device=self.device)
+        off = 0
+        for p in self.bucket.params:
+            k = p.numel()
+            self.optimizer.state[p] = {"step": self._adam_t, "exp_avg": self._adam_m[off:off + k].view_as(p),
+                                       "exp_avg_sq": self._adam_v[off:off + k].view_as(p)}
+            off += k
+
+    def _clip_and_step(self, norm_out, clip_n=None):
+        """clip_grad_norm_ + optimizer.step() (src/ppo.py:268-269)."""
+        if self._fused_adam:
+            g = self.optimizer.param_groups[0]
+            self.ops.clip_adam_(self.bucket.flat_param, self.bucket.flat_grad, self._adam_m, self._adam_v, self._lr_tensor,
+                                self._adam_t, self.max_grad_norm, clip_n, g["betas"], g["eps"], norm_out)
+        else:
+            fg = self.bucket.flat_grad if clip_n is None else self.bucket.flat_grad[:clip_n]
+            self.ops.grad_norm_clip_(fg, self.max_grad_norm, norm_out)
+            self.optimizer.step()
 
     def set_lr(self, lr):
         g = self.optimizer.param_groups[0]
@@ -306,6 +340,15 @@ class ppo:
             idx_ep = perms[ep]
             for start in range(0, B, M):
                 mb_inds = idx_ep[start:start + M]
+                if packed and self._mlp is not None:
+                    # one fused launch: rows are read through the permutation, gradients land in the bucket
+                    ops.mlp_ppo_step(b_obs, b_actions, self._rec, mb_inds, self.bucket.flat_param, self._mlp,
+                                     self.bucket.flat_grad, self.clip_coeff, self.entropy_coeff, self.value_coeff,
+                                     self.norm_adv, vmode, self._scalars[step])
+                    D.allreduce_mean_(self.bucket.flat_grad, self.world)
+                    self._clip_and_step(self._norms[step:step + 1])
+                    step += 1
+                    continue
                 mb = ops.gather(mb_inds, srcs, probe=self._probe) if self._probe is not None else ops.gather(mb_inds, srcs)
                 _, newlogprob, entropy, newvalue = self.policy.evaluate(mb[0], mb[1])
                 if packed:
@@ -319,8 +362,7 @@ class ppo:
                 self.bucket.zero_grad()
                 loss.backward()
                 D.allreduce_mean_(self.bucket.flat_grad, self.world)
-                ops.grad_norm_clip_(self.bucket.flat_grad, self.max_grad_norm, self._norms[step:step + 1])
-                self.optimizer.step()
+                self._clip_and_step(self._norms[step:step + 1])
                 step += 1
             if self.target_kl is not None:
                 # the reference compares the LAST minibatch's approx_kl (src/ppo.py:271-273)
@@ -345,6 +387,19 @@ class ppo:
         if self._probe_outs is None:
             self._probe_outs = [torch.empty((self.minibatch_size,) + tuple(t.shape[1:]), device=self.device) for t in srcs]
         self.ops.gather(perms[0][:self.minibatch_size], srcs, self._probe_outs, probe=probe)
+
+    def probe_mlp_step(self, events):
+        """One stand-alone K7 launch on the update's own first minibatch (gradients go to a scratch
+        bucket), with ``events`` recorded right around ``k_mlp_step`` inside the library call."""
+        perms = self._perm_static if self._perm_static is not None else self._perm_bufs[self._perm_flip ^ 1]
+        if self._probe_mlp_outs is None:
+            self._probe_mlp_outs = [torch.empty_like(self.bucket.flat_grad), torch.empty(self.ops.N_SCALARS, device=self.device)]
+        vmode = self.ops.VLOSS_CLIPPED if self.clip_vloss else self.ops.VLOSS_OLDVALUES
+        self.ops.mlp_ppo_step(self.buffer.states.reshape((-1,) + self.buffer.observation_shape),
+                              self.buffer.actions.reshape((-1,) + self.buffer.action_shape), self._rec,
+                              perms[0][:self.minibatch_size], self.bucket.flat_param, self._mlp, self._probe_mlp_outs[0],
+                              self.clip_coeff, self.entropy_coeff, self.value_coeff, self.norm_adv, vmode,
+                              self._probe_mlp_outs[1], events=events)
 
     def _rewind_rng(self, last_epoch_run):
         """Early stop at epoch e: upstream has drawn e+1 shuffles this update, we pre-drew E.

@@ -144,6 +144,7 @@ class robot_ppo:
         else:
             self._lr_tensor = None
             self.optimizer = torch.optim.Adam(self.policy.parameters(), lr=self.learning_rate, eps=1e-5)
+        self._adam_setup()
         self.pretrain_optimizer = torch.optim.Adam(self.expert.actor.parameters(), lr=self.learning_rate, eps=1e-5)
         self.total_returns, self.total_episode_lengths, self.x_indices = [], [], []
         self.episodic_returns = store_returns(self.num_envs, self.gamma)
@@ -154,6 +155,34 @@ class robot_ppo:
         self._norms = torch.zeros(n_steps, device=self.device)
 
     # ------------------------------------------------------------------ helpers
+    def _adam_setup(self):
+        """Flat Adam state for K6b (clip + Adam fused).  The torch optimizer object stays -- upstream code
+        reads ``optimizer.param_groups`` / ``state_dict()`` -- with its per-parameter state entries aliased to
+        views of the flat moment buffers and a shared device step counter."""
+        self._fused_adam = self.device.type == "cuda" and hasattr(self.ops, "clip_adam_")
+        if not self._fused_adam:
+            return
+        fp = self.bucket.flat_param
+        self._adam_m, self._adam_v = torch.zeros_like(fp), torch.zeros_like(fp)
+        self._adam_t = torch.zeros(1, device=self.device)
+        off = 0
+        for p in self.bucket.params:
+            k = p.numel()
+            self.optimizer.state[p] = {"step": self._adam_t, "exp_avg": self._adam_m[off:off + k].view_as(p),
+                                       "exp_avg_sq": self._adam_v[off:off + k].view_as(p)}
+            off += k
+
+    def _clip_and_step(self, norm_out, clip_n=None):
+        """clip_grad_norm_ + optimizer.step() (src/ppo.py:268-269)."""
+        if self._fused_adam:
+            g = self.optimizer.param_groups[0]
+            self.ops.clip_adam_(self.bucket.flat_param, self.bucket.flat_grad, self._adam_m, self._adam_v, self._lr_tensor,
+                                self._adam_t, self.max_grad_norm, clip_n, g["betas"], g["eps"], norm_out)
+        else:
+            fg = self.bucket.flat_grad if clip_n is None else self.bucket.flat_grad[:clip_n]
+            self.ops.grad_norm_clip_(fg, self.max_grad_norm, norm_out)
+            self.optimizer.step()
+
     def set_lr(self, lr):
         g = self.optimizer.param_groups[0]
         if self._lr_tensor is not None:
@@ -263,8 +292,7 @@ class robot_ppo:
                 expert_loss = nn.functional.mse_loss(b_actions[mb].requires_grad_(True), b_true_actions[mb])
                 self.bucket.zero_grad()
                 expert_loss.backward()
-                self.ops.grad_norm_clip_(self.bucket.flat_grad[:self.n_actor], self.max_grad_norm)
-                self.optimizer.step()
+                self._clip_and_step(self._norms[:1], self.n_actor)
 
     def test_env(self, writer):
         test_returns = store_returns(self.num_envs, self.gamma)
@@ -316,8 +344,7 @@ class robot_ppo:
                 self.bucket.zero_grad()
                 loss.backward()
                 D.allreduce_mean_(self.bucket.flat_grad, self.world)
-                ops.grad_norm_clip_(self.bucket.flat_grad[:self.n_actor], self.max_grad_norm, self._norms[step:step + 1])
-                self.optimizer.step()
+                self._clip_and_step(self._norms[step:step + 1], self.n_actor)
                 step += 1
             if self.target_kl is not None and float(self._scalars[step - 1, ops.S_KL]) > self.target_kl:
                 break

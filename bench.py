@@ -28,6 +28,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 MFMA peak (same guide, matrix cores table)
 
 
 def parse():
@@ -45,6 +46,7 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = usable cores, <=16)")
     ap.add_argument("--no-probe", action="store_true", help="do not time the gather kernel with HIP events")
     ap.add_argument("--no-graph", action="store_true", help="run the update eagerly instead of as a hipGraph")
+    ap.add_argument("--no-fused-mlp", action="store_true", help="per-op path (K3 + torch nets + K5) instead of K7")
     return ap.parse_args()
 
 
@@ -149,6 +151,7 @@ def main():
     torch.manual_seed(1)
     hp = hyper(args, world)
     hp["device"] = dev
+    hp["fused_mlp"] = not args.no_fused_mlp
     agent = ppo(hp)
     T, N, Dm, A = args.num_steps, agent.num_envs, args.obs_dim, args.act_dim
     data = synth_buffers(T, N, Dm, A, 1234 + rank)
@@ -165,13 +168,22 @@ def main():
     if args.no_graph:
         agent.use_graph = False
 
+    step_no = [0]
+    mlp_events = []
+
     def one_step():
         returns, advantages = agent.advantages(next_obs, next_done)
         agent.update(returns, advantages)
-        if probe.on and not args.no_probe:
-            # the update replays as a hipGraph, whose kernels cannot carry readable events: time one
-            # extra stand-alone launch of the same gather (same indices, same sources) per step instead
-            agent.probe_gather(probe)
+        step_no[0] += 1
+        if probe.on and not args.no_probe and step_no[0] % 4 == 1:
+            # The update replays as a hipGraph, whose kernels cannot carry readable events: every 4th
+            # step, time ONE extra stand-alone launch of the dominant kernel on the update's own inputs.
+            if agent._mlp is not None:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                agent.probe_mlp_step(ev)       # events recorded inside the library, around k_mlp_step only
+                mlp_events.append(ev)
+            else:
+                agent.probe_gather(probe)
 
     log(f"rank {rank}/{world}: setup done, {args.warmup} warm-up steps")
     for _ in range(args.warmup):
@@ -199,24 +211,36 @@ def main():
         return
     env_steps = world * N * T * args.steps
     M = agent.minibatch_size
-    gather_bytes = M * (8 * Dm + 8 * A + 36)          # idx + 6 streams read + written
-    g_ms = probe.mean_ms()
+
+    def pmc(name):
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            return json.load(open(path)).get("hbm_bytes_per_launch")
+        except Exception:
+            return None
+
     roofline = None
-    if g_ms:
+    if mlp_events:
+        from aur_ppo_amd import hip_ops as H
+        ms = float(np.mean([b.elapsed_time(e) for b, e in mlp_events]))
+        flops = H.mlp_step_flops(agent._mlp, M)
+        ach = flops / (ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "k_mlp_step (K7: gather + actor/critic forward + PPO loss + backward)",
+                    "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": pmc("mlp_pmc.json"),
+                    "flops_per_launch": flops, "avg_launch_us": round(ms * 1e3, 2), "launches_timed": len(mlp_events),
+                    "algorithmic_hbm_bytes_per_launch": M * (4 * (Dm + A + 4) + 4),
+                    "how": "hipEvent pair recorded inside the library around k_mlp_step, one extra stand-alone "
+                           "launch every 4th step on the update's own minibatch (the update itself is a hipGraph)"}
+    elif probe.pairs:
+        gather_bytes = M * (8 * Dm + 8 * A + 36)          # idx + 6 streams read + written
+        g_ms = probe.mean_ms()
         ach = gather_bytes / (g_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "gather_pmc.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
         roofline = {"bound": "hbm", "kernel": "k_gather", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc("gather_pmc.json"),
                     "bytes_per_launch": gather_bytes, "avg_launch_us": round(g_ms * 1e3, 2),
                     "launches_timed": len(probe.pairs),
-                    "how": "HIP-event pairs around one stand-alone launch per step of the update's own gather "
-                           "(the update itself replays as a hipGraph)"}
+                    "how": "HIP-event pairs around one stand-alone launch every 4th step of the update's own gather"}
     out = {"metric": "env-steps/sec through GAE+PPO-update at num_envs=4096,T=128; 1/2/4/8 GPU",
            "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -225,7 +249,8 @@ def main():
                                   f"T={T}, E={args.epochs}, {args.minibatches} minibatches/epoch (M={M}), 2x64 tanh "
                                   "MLP actor+critic, Adam, random-init weights",
                       "global_num_envs": N * world, "num_steps": T, "parallelism": f"env-shard dp{world}",
-                      "update_launch": "hipGraph" if agent._graph is not None else "eager"},
+                      "update_launch": "hipGraph" if agent._graph is not None else "eager",
+                      "minibatch_step": "K7 fused MLP step" if agent._mlp is not None else "K3 + torch nets + K5"},
            "roofline": roofline}
     if world == 1 and args.cpu_baseline_updates > 0:
         out["cpu_baseline"] = cpu_baseline(args, data, init_sd, args.cpu_baseline_updates)

@@ -140,6 +140,36 @@ int aurppo_loss_fwd_bwd_packed_f32(const float* newlogp, const float* newv, cons
                                    float* g_newlogp, float* g_newv, float* g_entropy, void* workspace,
                                    void* stream);
 
+/* ---- K7: fused minibatch step for the MLP actor-critic -----------------------------------------
+ * One launch sequence replaces, for the reference's MLP policy (actor_critic over two Tanh hidden
+ * layers of `hidden` units, Gaussian head with state-independent log-std; src/models/actor_critic.py:
+ * 8-51, src/nets/nets.py:19-53), everything between "mb_inds chosen" and "gradients ready":
+ *   gathers (src/ppo.py:219-220,225,236,251-257) + evaluate() (src/ppo.py:220) + the loss block
+ *   (src/ppo.py:225-264) + loss.backward() (src/ppo.py:267).
+ * obs (B,D), actions (B,A) and rec (B,4) = {old_logp, adv, ret, old_v} are the flattened rollout
+ * buffers, idx (M,) the minibatch slice of the epoch permutation.  `params` is the flat parameter
+ * bucket, layout_h 13 float offsets into it {w1,b1,w2,b2,w3,b3} for the actor, the same for the
+ * critic, then actor_logstd (nn.Linear layout: weight[out][in]).  `grads` (n_params floats) is
+ * OVERWRITTEN with d loss / d params in the same layout; out_scalars as aurppo_loss_fwd_bwd_f32.
+ * Built for hidden = 64, even D <= 64, A <= 16; other shapes return AURPPO_ESHAPE (callers then use
+ * the per-op path).  workspace: aurppo_mlp_workspace_bytes(n_params) bytes, 16-byte aligned.      */
+size_t aurppo_mlp_workspace_bytes(int n_params);
+int aurppo_mlp_ppo_step_f32(const float* obs, const float* actions, const float* rec,
+                            const int32_t* idx, int M, int D, int A, int hidden, const float* params,
+                            const int* layout_h, int n_params, float* grads, double clip,
+                            double ent_coef, double vf_coef, int norm_adv, int vloss_mode,
+                            float* out_scalars, void* workspace, void* stream);
+
+/* Measurement variant: identical work, and the two caller-owned hipEvent_t handles (either may be NULL)
+ * are recorded on `stream` immediately before and after the main kernel (k_mlp_step) -- bench.py times
+ * the kernel with them (hipEventElapsedTime) without a profiler attached.                           */
+int aurppo_mlp_ppo_step_ev_f32(const float* obs, const float* actions, const float* rec,
+                               const int32_t* idx, int M, int D, int A, int hidden, const float* params,
+                               const int* layout_h, int n_params, float* grads, double clip,
+                               double ent_coef, double vf_coef, int norm_adv, int vloss_mode,
+                               float* out_scalars, void* workspace, void* stream, void* ev_begin,
+                               void* ev_end);
+
 /* ---- K6: global-norm gradient clip over one flat bucket -------------------------------------
  * Replaces nn.utils.clip_grad_norm_(params, max_norm) (src/ppo.py:268; src/robot_ppo.py:401):
  * norm = ||g||_2, g *= min(1, max_norm / (norm + 1e-6)).  out_norm: 1 float (device), the
@@ -147,6 +177,17 @@ int aurppo_loss_fwd_bwd_packed_f32(const float* newlogp, const float* newv, cons
 size_t aurppo_clip_workspace_bytes(int64_t n);
 int aurppo_grad_norm_clip_f32(float* flat_grads, int64_t n, double max_norm, float* out_norm,
                               void* workspace, void* stream);
+
+/* K6b: clip + Adam fused over the flat bucket -- clip_grad_norm_ over the first clip_n elements
+ * (src/ppo.py:268 clips everything, clip_n = n; src/robot_ppo.py:401 the actor's slice only) followed
+ * by torch.optim.Adam's step (src/ppo.py:80,269; betas, eps as given) on all n elements.  lr_dev and
+ * step_dev are 1-float DEVICE scalars: the learning rate (so an annealed rate works under hipGraph
+ * replay) and the step counter, which this call increments.  exp_avg / exp_avg_sq are the moment
+ * buffers (n floats each, zero-initialised by the caller).  workspace: aurppo_clip_workspace_bytes(n). */
+int aurppo_clip_adam_f32(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                         int64_t clip_n, double max_norm, const float* lr_dev, float* step_dev,
+                         double beta1, double beta2, double eps, float* out_norm, void* workspace,
+                         void* stream);
 
 #ifdef __cplusplus
 }

@@ -343,3 +343,34 @@ def test_gae_pack_record_and_packed_loss_match_unpacked(H, CO):
                            rec_mb[:, 2].contiguous(), ent, 0.2, 0.01, 0.5, True, mode)
         for x, y in zip(a, b):
             assert torch.equal(x, y)
+
+
+# ---------------------------------------------------------------------------------- K6b
+@pytest.mark.parametrize("n,clip_n", [(17104, None), (1000, 400), (3, 3)])
+def test_clip_adam_matches_torch_clip_then_adam(H, n, clip_n):
+    torch.manual_seed(n)
+    p0 = torch.randn(n, device="cuda")
+    p_ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([p_ref], lr=3e-4, eps=1e-5)
+    p, m, v = p0.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    lr, t = torch.tensor([3e-4], device="cuda"), torch.zeros(1, device="cuda")
+    for step in range(5):
+        g = torch.randn(n, device="cuda") * (10.0 if step % 2 else 1e-3)
+        lr.fill_(3e-4 * (1 - step / 5))
+        opt.param_groups[0]["lr"] = 3e-4 * (1 - step / 5)
+        p_ref.grad = g.clone()
+        k = n if clip_n is None else clip_n
+        # torch: clip the leading slice only, then Adam on everything
+        sl = torch.nn.Parameter(torch.zeros(k, device="cuda"))
+        sl.grad = p_ref.grad[:k]
+        ref_norm = torch.nn.utils.clip_grad_norm_([sl], 0.5)
+        opt.step()
+        gg = g.clone()
+        norm = H.clip_adam_(p, gg, m, v, lr, t, 0.5, clip_n)
+        torch.testing.assert_close(norm[0], ref_norm, rtol=1e-5, atol=1e-9)
+        torch.testing.assert_close(gg, p_ref.grad, rtol=1e-5, atol=1e-10)
+        torch.testing.assert_close(p, p_ref.data, rtol=1e-6, atol=1e-7)
+    assert float(t) == 5.0
+    st = opt.state[p_ref]
+    torch.testing.assert_close(m, st["exp_avg"], rtol=1e-5, atol=1e-9)
+    torch.testing.assert_close(v, st["exp_avg_sq"], rtol=1e-5, atol=1e-12)

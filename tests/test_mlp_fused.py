@@ -1,0 +1,82 @@
+"""GPU: K7 (fused gather + MLP forward + PPO loss + backward) vs the per-op autograd path."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(T, N, D, A, seed=0):
+    from aur_ppo_amd import hip_ops as H
+    from aur_ppo_amd.actor_critic import actor_critic
+    from aur_ppo_amd.flat import FlatBucket
+    torch.manual_seed(seed)
+    pol = actor_critic(D, (A,), 64, 2, 0.0, True).cuda()
+    with torch.no_grad():
+        pol.actor_logstd.copy_(0.3 * torch.randn(1, A))
+        for p in pol.parameters():          # make every layer matter (head init is 0.01-scaled)
+            p.add_(0.05 * torch.randn_like(p))
+    bucket = FlatBucket(pol.parameters())
+    B = T * N
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    obs = torch.randn(B, D, device="cuda", generator=g)
+    act = torch.randn(B, A, device="cuda", generator=g)
+    with torch.no_grad():
+        _, lp, _, v = pol.evaluate(obs, act)
+    rec = torch.stack([lp + 0.2 * torch.randn(B, device="cuda", generator=g), 2 * torch.randn(B, device="cuda", generator=g),
+                       v.view(-1) + torch.randn(B, device="cuda", generator=g),
+                       v.view(-1) + 0.1 * torch.randn(B, device="cuda", generator=g)], 1).contiguous()
+    return H, pol, bucket, obs, act, rec
+
+
+@pytest.mark.parametrize("T,N,D,A,M", [(8, 64, 64, 6, 256), (16, 64, 64, 6, 1000), (4, 32, 4, 1, 77), (8, 32, 32, 16, 128),
+                                         (128, 1024, 64, 6, 131072)])
+@pytest.mark.parametrize("norm_adv,vmode", [(True, 1), (False, 2), (True, 0)])
+def test_fused_step_matches_autograd_path(T, N, D, A, M, norm_adv, vmode):
+    H, pol, bucket, obs, act, rec = _setup(T, N, D, A)
+    B = T * N
+    idx = torch.randperm(B, device="cuda")[:M].int()
+    lay = H.mlp_layout(pol, bucket)
+    assert lay is not None and lay["D"] == D and lay["A"] == A
+    # reference: the existing per-op path (K3 gather -> torch evaluate -> K5 loss -> autograd)
+    mb = H.gather(idx, [obs, act, rec])
+    _, nlp, ent, nv = pol.evaluate(mb[0], mb[1])
+    sc_ref = torch.empty(9, device="cuda")
+    loss = H.ppo_loss_packed(nlp, nv, ent, mb[2], 0.2, 0.01, 0.5, norm_adv, vmode, sc_ref)
+    bucket.zero_grad()
+    loss.backward()
+    g_ref = bucket.flat_grad[:lay["n_params"]].clone()
+    # K7
+    g_out = torch.full_like(bucket.flat_grad, float("nan"))
+    sc = H.mlp_ppo_step(obs, act, rec, idx, bucket.flat_param, lay, g_out, 0.2, 0.01, 0.5, norm_adv, vmode)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(sc.cpu().numpy(), sc_ref.cpu().numpy(), rtol=2e-5, atol=2e-6)
+    g = g_out[:lay["n_params"]]
+    assert torch.isfinite(g).all()
+    scale = float(g_ref.abs().max())
+    err = float((g - g_ref).abs().max())
+    assert err <= 2e-5 * scale + 1e-8, (err, scale)
+    # per-parameter relative check where the gradient is not tiny
+    names = ["actor_logstd"] + [f"{n}.{k}" for n in ("actor", "critic") for k in ("w1", "b1", "w2", "b2", "w3", "b3")]
+    off = 0
+    for p_, nm in zip(bucket.params, names):
+        k = p_.numel()
+        a, b = g[off:off + k], g_ref[off:off + k]
+        s = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 5e-5 * s + 1e-9, (nm, float((a - b).abs().max()), s)
+        off += k
+
+
+def test_fused_step_rejects_unsupported_shapes():
+    H, pol, bucket, obs, act, rec = _setup(4, 32, 64, 6)
+    lay = dict(H.mlp_layout(pol, bucket))
+    idx = torch.arange(16, device="cuda", dtype=torch.int32)
+    lay["D"] = 63
+    with pytest.raises((RuntimeError, ValueError)):
+        H.mlp_ppo_step(obs, act, rec, idx, bucket.flat_param, lay, bucket.flat_grad, 0.2, 0.0, 0.5)
+    from aur_ppo_amd.actor_critic import actor_critic
+    from aur_ppo_amd.flat import FlatBucket
+    disc = actor_critic(4, 2, 64, 2, 0.0, False).cuda()
+    assert H.mlp_layout(disc, FlatBucket(disc.parameters())) is None          # discrete head: per-op path
+    wide = actor_critic(64, (6,), 128, 2, 0.0, True).cuda()
+    assert H.mlp_layout(wide, FlatBucket(wide.parameters())) is None

@@ -11,7 +11,7 @@ import csv, glob
 f = glob.glob("gpurun_out/kp_$tag/**/*kernel_stats.csv", recursive=True)[0]
 for r in csv.DictReader(open(f)):
     n = r["Name"]
-    if any(k in n for k in ("k_gather", "k_gae", "k_loss", "k_adv", "k_fy", "k_clip", "k_sqnorm", "index_select", "copyBuffer")):
-        print(f"$tag {n[:70]:70s} calls={r['Calls']:>5s} avg_us={float(r['AverageNs'])/1e3:9.2f} min_us={float(r['MinNs'])/1e3:9.2f}")
+    if any(k in n for k in ("k_gather", "k_gae", "k_loss", "k_adv", "k_fy", "k_mt_", "k_mlp", "k_clip", "k_sqnorm", "index_select", "copyBuffer")):
+        print(f"$tag {n[:70]:70s} calls={r['Calls']:>5s} avg_us={float(r['AverageNs'])/1e3:9.2f} min_us={float(r['MinNs'])/1e3:9.2f} max_us={float(r['MaxNs'])/1e3:9.2f}")
 PY
 rm -rf gpurun_out/kp_$tag
