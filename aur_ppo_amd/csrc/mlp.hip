@@ -637,10 +637,13 @@ static int mlp_step_impl(const float* obs, const float* actions, const float* re
                        reinterpret_cast<double (*)[2]>(stats));
     AURPPO_LAUNCH_CHECK("k_adv_stats_idx");
     const int n_tiles = (M + R - 1) / R;
-    // One persistent workgroup per CU.  AURPPO_MLP_SPARE_CUS (experiment knob, default 0) leaves CUs free
-    // for the side-stream shuffle kernels; measured: no gain (6.44 vs 6.45 ms/update), the shuffle's own
-    // length is what bounds the update, not CU sharing.
-    static int cus = 0, spare = 0;
+    // One persistent workgroup per CU, minus one CU per XCD (AURPPO_MLP_SPARE_CUS, default 8): workgroups
+    // are dealt round-robin over the 8 XCDs, so a grid of 248 leaves every XCD one free CU for the
+    // single-workgroup shuffle kernels that run concurrently on the side stream.  A statically strided
+    // persistent kernel runs at the pace of its slowest workgroup, and sharing a CU with the 16-wave
+    // k_fy_accept stretched 92 % of the launches (rocprof in-situ: mean 263 us, p90 380 us with spare = 0, 1
+    // or 2; mean 214 us, p90 224 us with 8).
+    static int cus = 0, spare = 8;
     if (!cus) {
         int dev = 0;
         hipDeviceProp_t prop;

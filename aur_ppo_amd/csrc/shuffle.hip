@@ -25,19 +25,26 @@
 //      almost always empty, so each element resolves with a handful of L2-resident loads.
 // The generator state (key[624], pos) stays on the device between calls, like numpy's global stream.
 #include <math.h>
+#include <string.h>
 
 #include "common.h"
 
 struct aurppo_rng {
-    uint32_t* d_state;  // key[624] then pos
-    int32_t* d_j;       // swap targets
-    int32_t* d_head;    // list head per target position
-    int32_t* d_next;    // list link per step
-    int32_t* d_tmp;     // out-of-place result for the in-place API
-    uint32_t* d_words;  // tempered draws for the shuffle in flight
-    int32_t* d_meta;    // [0] words consumed so far, [1] next index i to fill, [2] sticky error, [3] words in buffer
+    uint32_t* d_state;   // key[624] + pos: the generator at the stream ORIGIN (last seed / set_state)
+    uint32_t* d_last;    // [624] untempered form of the last block written to the ring
+    uint32_t* d_ring;    // ring of tempered draws; stream word g lives at d_ring[g % ring_cap]
+    long long* d_pos;    // [0] words written (stream offset), [1] words consumed (read cursor), [2] sticky error
+    int32_t* d_j;        // swap targets
+    int32_t* d_head;     // list head per target position
+    int32_t* d_next;     // list link per step
+    int32_t* d_tmp;      // out-of-place result for the in-place API
+    int32_t* d_meta;     // accept scratch
     int max_n;
-    size_t words_cap;
+    size_t ring_cap;     // words, a multiple of 624
+    hipStream_t fill_stream;   // the twist runs one shuffle ahead of its consumer on this stream
+    hipEvent_t ev_fill[2], ev_acc[2], ev_sync;
+    long seq;            // shuffles issued since the last (re)seed
+    double primed_need;  // words-per-shuffle the look-ahead fill was sized for (0: nothing in flight)
 };
 
 namespace {
@@ -82,87 +89,111 @@ __device__ __forceinline__ uint32_t mt_untemper(uint32_t y) {
 
 constexpr int kFillThreads = 256;
 
-// Tempered words of the stream from the generator's current position on:
-//   words[0 .. 624-pos) = temper(state[pos ..]), then `nblk` freshly twisted blocks.  The generator state
-// itself is NOT advanced here; k_fy_commit re-derives it from the words actually consumed.
-__global__ __launch_bounds__(kFillThreads) void k_mt_fill(const uint32_t* __restrict__ state,
-                                                          uint32_t* __restrict__ words, int nblk,
-                                                          int32_t* __restrict__ meta, int first) {
+// Append freshly twisted blocks to the ring so that (words written - words consumed) reaches `target`
+// words (at most nblk_max blocks).  Continues from d_last; all bookkeeping is on the device.
+__global__ __launch_bounds__(kFillThreads) void k_mt_fill(uint32_t* __restrict__ last, uint32_t* __restrict__ ring,
+                                                          long long ring_cap, long long* __restrict__ posv,
+                                                          long long target, int nblk_max) {
     __shared__ uint32_t buf[2][kMtN];
     const int tid = threadIdx.x;
-    if (!first && meta[1] < 1) return;   // continuation launch, nothing left to draw
-    for (int k = tid; k < kMtN; k += kFillThreads) buf[0][k] = state[k];
-    const int pos = (int)state[kMtN];
+    const long long S = posv[0];
+    const long long cur = posv[1];   // may lag a concurrently running consumer: a lower bound, which is safe
+    long long want = target - (S - cur);
+    int nblk = want > 0 ? (int)((want + kMtN - 1) / kMtN) : 0;
+    if (nblk > nblk_max) nblk = nblk_max;
+    if (nblk == 0) return;
+    for (int k = tid; k < kMtN; k += kFillThreads) buf[0][k] = last[k];
     __syncthreads();
-    size_t out = first ? 0 : (size_t)meta[3];
-    if (first) {
-        for (int k = pos + tid; k < kMtN; k += kFillThreads) words[k - pos] = mt_temper(buf[0][k]);
-        out = (size_t)(kMtN - pos);
-    } else {
-        // continuation: resume from the last block written (its untempered form is rebuilt from the words)
-        for (int k = tid; k < kMtN; k += kFillThreads) buf[0][k] = mt_untemper(words[out - kMtN + k]);
-        __syncthreads();
-    }
-    int cur = 0;
+    long long out = S;
+    int cb = 0;
     for (int b = 0; b < nblk; ++b) {
-        const uint32_t* o = buf[cur];
-        uint32_t* w = buf[cur ^ 1];
-        // phase 1: k in [0, 227)
-        if (tid < kMtD) w[tid] = o[tid + kMtM] ^ mt_mix(o[tid], o[tid + 1]);
+        const uint32_t* o = buf[cb];
+        uint32_t* w = buf[cb ^ 1];
+        if (tid < kMtD) w[tid] = o[tid + kMtM] ^ mt_mix(o[tid], o[tid + 1]);          // k in [0, 227)
         __syncthreads();
-        // phase 2: k in [227, 454)
-        if (tid < kMtD) {
+        if (tid < kMtD) {                                                                // k in [227, 454)
             const int k = tid + kMtD;
             w[k] = w[k - kMtD] ^ mt_mix(o[k], o[k + 1]);
         }
         __syncthreads();
-        // phase 3: k in [454, 624)
-        if (tid < kMtN - 2 * kMtD) {
+        if (tid < kMtN - 2 * kMtD) {                                                     // k in [454, 624)
             const int k = tid + 2 * kMtD;
             w[k] = w[k - kMtD] ^ mt_mix(o[k], k == kMtN - 1 ? w[0] : o[k + 1]);
         }
         __syncthreads();
-        for (int k = tid; k < kMtN; k += kFillThreads) words[out + k] = mt_temper(w[k]);
+        for (int k = tid; k < kMtN; k += kFillThreads) ring[(out + k) % ring_cap] = mt_temper(w[k]);
         out += kMtN;
-        cur ^= 1;
+        cb ^= 1;
     }
-    if (tid == 0) meta[3] = (int32_t)out;
+    for (int k = tid; k < kMtN; k += kFillThreads) last[k] = buf[cb][k];
+    if (tid == 0) posv[0] = out;
+}
+
+// (Re)start the stream at a generator state: ring[0 .. 624-pos) = temper(key[pos..]), last block = key
+__global__ __launch_bounds__(kFillThreads) void k_mt_origin(const uint32_t* __restrict__ state,
+                                                            uint32_t* __restrict__ last, uint32_t* __restrict__ ring,
+                                                            long long* __restrict__ posv) {
+    const int tid = threadIdx.x;
+    const int pos = (int)state[kMtN];
+    for (int k = tid; k < kMtN; k += kFillThreads) {
+        last[k] = state[k];
+        if (k >= pos) ring[k - pos] = mt_temper(state[k]);
+    }
+    if (tid == 0) {
+        posv[0] = kMtN - pos;
+        posv[1] = 0;
+        posv[2] = 0;
+    }
+}
+
+// Generator state at the read cursor, numpy's (key, pos): the untempered 624-word block holding the
+// cursor (pos = 624 when the cursor sits exactly on a block boundary: numpy twists lazily).
+__global__ __launch_bounds__(kFillThreads) void k_state_at_cursor(const uint32_t* __restrict__ state,
+                                                                  const uint32_t* __restrict__ ring,
+                                                                  long long ring_cap,
+                                                                  const long long* __restrict__ posv,
+                                                                  uint32_t* __restrict__ out) {
+    const int tid = threadIdx.x;
+    const int pos0 = (int)state[kMtN];
+    const long long p = (long long)pos0 + posv[1];
+    long long blk = p / kMtN;
+    int pos = (int)(p % kMtN);
+    if (pos == 0 && p > 0) {
+        blk -= 1;
+        pos = kMtN;
+    }
+    for (int k = tid; k < kMtN; k += kFillThreads)
+        out[k] = blk > 0 ? mt_untemper(ring[(blk * kMtN - pos0 + k) % ring_cap]) : state[k];
+    if (tid == 0) out[kMtN] = (uint32_t)pos;
 }
 
 constexpr int kAccThreads = 1024;
 constexpr int kWpt = 8;                       // draws per thread per step
 constexpr int kAccStep = kAccThreads * kWpt;  // 8192 draws per step
 
-__global__ __launch_bounds__(kAccThreads) void k_fy_accept(const uint32_t* __restrict__ words,
+__global__ __launch_bounds__(kAccThreads) void k_fy_accept(const uint32_t* __restrict__ ring, long long ring_cap,
                                                            int32_t* __restrict__ j, int n,
-                                                           int32_t* __restrict__ meta, int first) {
+                                                           long long* __restrict__ posv) {
     __shared__ int s_wsum[kAccThreads / kWave];
     __shared__ int s_changed[2];
     __shared__ int s_end;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
-    if (first) {
-        if (tid == 0) {
-            meta[0] = 0;
-            meta[1] = n - 1;
-            meta[2] = 0;
-        }
-    }
     if (tid == 0) s_changed[0] = s_changed[1] = 0;
     __syncthreads();
-    long cursor = first ? 0 : meta[0];        // words consumed so far
-    int i_cur = first ? n - 1 : meta[1];      // next index to draw a target for
-    const long avail = meta[3];
+    long long cursor = posv[1];               // stream offset of the next unread draw
+    const long long avail = posv[0];          // draws written so far (the fill for this shuffle has completed)
+    int i_cur = n - 1;                        // next index to draw a target for
     float rate = 0.72f;                        // acceptance rate guess, refreshed every step
     // this step's draws are fetched one step ahead (every step but the last consumes exactly kAccStep)
     uint32_t ynext[kWpt];
-    auto fetch = [&](long cur) {
-        const long b0 = cur + (long)tid * kWpt;
+    auto fetch = [&](long long cur) {
+        const long long b0 = cur + (long long)tid * kWpt;
 #pragma unroll
-        for (int u = 0; u < kWpt; ++u) ynext[u] = (b0 + u) < avail ? words[b0 + u] : 0u;
+        for (int u = 0; u < kWpt; ++u) ynext[u] = (b0 + u) < avail ? ring[(b0 + u) % ring_cap] : 0u;
     };
     fetch(cursor);
     while (i_cur >= 1 && cursor < avail) {
-        const long base = cursor + (long)tid * kWpt;
+        const long long base = cursor + (long long)tid * kWpt;
         uint32_t y[kWpt];
         int nhave = 0;                             // my draws that exist (a prefix of the 8)
 #pragma unroll
@@ -255,7 +286,7 @@ __global__ __launch_bounds__(kAccThreads) void k_fy_accept(const uint32_t* __res
         __syncthreads();
         if (cnt > 0 && my_end_i == 0) s_end = tid * kWpt + consumed;   // unique thread: filled i = 1
         __syncthreads();
-        long step_words = avail - cursor < kAccStep ? avail - cursor : kAccStep;
+        long long step_words = avail - cursor < kAccStep ? avail - cursor : kAccStep;
         if (total >= i_cur) step_words = s_end;
         rate = step_words > 0 ? (float)total / (float)step_words : rate;
         i_cur -= total;
@@ -263,38 +294,9 @@ __global__ __launch_bounds__(kAccThreads) void k_fy_accept(const uint32_t* __res
         __syncthreads();
     }
     if (tid == 0) {
-        meta[0] = (int32_t)cursor;
-        meta[1] = i_cur;
+        posv[1] = cursor;
+        if (i_cur >= 1) posv[2] = 1;   // ran out of draws before the shuffle finished: sticky error
     }
-}
-
-// After a shuffle: move the generator to where numpy's would be -- the 624-word block holding the
-// read cursor (untempered back from the word buffer) and the offset inside it; flag an exhausted buffer.
-__global__ __launch_bounds__(kFillThreads) void k_fy_commit(uint32_t* __restrict__ state,
-                                                            const uint32_t* __restrict__ words,
-                                                            int32_t* __restrict__ meta) {
-    const int tid = threadIdx.x;
-    const int pos0 = (int)state[kMtN];
-    const long consumed = meta[0];
-    if (meta[1] >= 1) {           // ran out of words before the shuffle finished (astronomically unlikely)
-        if (tid == 0) meta[2] = 1;
-        return;
-    }
-    // stream position measured from the start of the generator's current block
-    const long p = (long)pos0 + consumed;
-    long blk = p / kMtN;
-    int pos = (int)(p % kMtN);
-    if (pos == 0 && p > 0) {      // numpy sits at pos = 624 of the previous block until the next draw
-        blk -= 1;
-        pos = kMtN;
-    }
-    __syncthreads();
-    if (blk > 0) {
-        // words[] starts at offset pos0 of block 0, so block b >= 1 begins at word (b*624 - pos0)
-        const long w0 = blk * kMtN - pos0;
-        for (int k = tid; k < kMtN; k += kFillThreads) state[k] = mt_untemper(words[w0 + k]);
-    }
-    if (tid == 0) state[kMtN] = (uint32_t)pos;
 }
 
 __global__ void k_fy_link(const int32_t* __restrict__ j, int32_t* __restrict__ head, int32_t* __restrict__ next,
@@ -356,41 +358,74 @@ static double expected_draws(int n) {
     long lo = 1;
     while (lo <= (long)n - 1) {                 // octave [lo, 2lo): mask + 1 = 2lo
         const long hi = (2 * lo - 1 < (long)n - 1) ? 2 * lo - 1 : (long)n - 1;
-        // sum_{i=lo..hi} 2lo / (i+1)  ~  2lo * ln((hi+1.5)/(lo+0.5))
         e += 2.0 * (double)lo * log(((double)hi + 1.5) / ((double)lo + 0.5));
         lo *= 2;
     }
     return e;
 }
 
+// Draws one shuffle of n may need: expectation + 12 sigma (sigma <= sqrt(2n)); exceeding it trips the
+// sticky error flag instead of producing a wrong permutation.
+static double need_words(int n) { return expected_draws(n) + 12.0 * sqrt(2.0 * (double)n) + 2.0 * kMtN; }
+
+static int enqueue_fill(aurppo_rng* rng, double need, hipStream_t after, int slot) {
+    // inventory target 2*need: one shuffle may be consuming while the next one's draws are produced
+    AURPPO_HIP_TRY(hipEventRecord(rng->ev_sync, after));
+    AURPPO_HIP_TRY(hipStreamWaitEvent(rng->fill_stream, rng->ev_sync, 0));
+    const int nblk_max = (int)(2.0 * need / kMtN) + 2;
+    hipLaunchKernelGGL(k_mt_fill, dim3(1), dim3(kFillThreads), 0, rng->fill_stream, rng->d_last, rng->d_ring,
+                       (long long)rng->ring_cap, rng->d_pos, (long long)(2.0 * need), nblk_max);
+    AURPPO_LAUNCH_CHECK("k_mt_fill");
+    AURPPO_HIP_TRY(hipEventRecord(rng->ev_fill[slot], rng->fill_stream));
+    return AURPPO_OK;
+}
+
 int permute_once(aurppo_rng* rng, const int32_t* in, int32_t* out, int n, hipStream_t s) {
-    // stage 1 covers the expected draw count + 12 sigma (sigma <= sqrt(2n)); stage 2 (early-exits on the
-    // device when stage 1 finished) doubles the margin; beyond that the sticky error flag is raised.
-    const double e = expected_draws(n);
-    const double sigma = sqrt(2.0 * (double)n);
-    int nblk1 = (int)((e + 12.0 * sigma) / kMtN) + 2;
-    int nblk2 = (int)((0.05 * e + 40.0 * sigma) / kMtN) + 2;
-    const size_t need = (size_t)(nblk1 + nblk2 + 1) * kMtN;
-    if (need > rng->words_cap) {
-        aurppo_set_error("shuffle: word buffer too small for n=%d (%zu > %zu)", n, need, rng->words_cap);
+    const double need = need_words(n);
+    if (2.0 * need + 4.0 * kMtN > (double)rng->ring_cap) {
+        aurppo_set_error("shuffle: word ring too small for n=%d", n);
         return AURPPO_ESHAPE;
     }
-    for (int stage = 0; stage < 2; ++stage) {
-        hipLaunchKernelGGL(k_mt_fill, dim3(1), dim3(kFillThreads), 0, s, rng->d_state, rng->d_words,
-                           stage ? nblk2 : nblk1, rng->d_meta, stage == 0);
-        AURPPO_LAUNCH_CHECK("k_mt_fill");
-        hipLaunchKernelGGL(k_fy_accept, dim3(1), dim3(kAccThreads), 0, s, rng->d_words, rng->d_j, n, rng->d_meta,
-                           stage == 0);
-        AURPPO_LAUNCH_CHECK("k_fy_accept");
+    const int slot = (int)(rng->seq & 1);
+    if (rng->primed_need < need) {
+        // nothing (or too little) in flight for this size: produce this shuffle's draws now
+        int rc = enqueue_fill(rng, need, s, slot);
+        if (rc != AURPPO_OK) return rc;
+        rng->primed_need = need;
     }
-    hipLaunchKernelGGL(k_fy_commit, dim3(1), dim3(kFillThreads), 0, s, rng->d_state, rng->d_words, rng->d_meta);
-    AURPPO_LAUNCH_CHECK("k_fy_commit");
+    AURPPO_HIP_TRY(hipStreamWaitEvent(s, rng->ev_fill[slot], 0));
+    hipLaunchKernelGGL(k_fy_accept, dim3(1), dim3(kAccThreads), 0, s, rng->d_ring, (long long)rng->ring_cap, rng->d_j, n,
+                       rng->d_pos);
+    AURPPO_LAUNCH_CHECK("k_fy_accept");
+    // Look-ahead: the NEXT shuffle's draws (assumed the same size) are twisted on the fill stream while
+    // this shuffle's accept / link / resolve run here.  It is ordered after the PREVIOUS accept (ev_acc of
+    // the other slot), so the cursor it reads is at most one shuffle stale -- what the 2*need target covers.
+    if (rng->seq > 0) AURPPO_HIP_TRY(hipStreamWaitEvent(rng->fill_stream, rng->ev_acc[slot ^ 1], 0));
+    {
+        const int nblk_max = (int)(2.0 * need / kMtN) + 2;
+        hipLaunchKernelGGL(k_mt_fill, dim3(1), dim3(kFillThreads), 0, rng->fill_stream, rng->d_last, rng->d_ring,
+                           (long long)rng->ring_cap, rng->d_pos, (long long)(2.0 * need), nblk_max);
+        AURPPO_LAUNCH_CHECK("k_mt_fill");
+        AURPPO_HIP_TRY(hipEventRecord(rng->ev_fill[slot ^ 1], rng->fill_stream));
+    }
+    AURPPO_HIP_TRY(hipEventRecord(rng->ev_acc[slot], s));
     AURPPO_HIP_TRY(hipMemsetAsync(rng->d_head, 0xff, sizeof(int32_t) * (size_t)n, s));
     const int grid = (n + 255) / 256;
     hipLaunchKernelGGL(k_fy_link, dim3(grid), dim3(256), 0, s, rng->d_j, rng->d_head, rng->d_next, n);
     AURPPO_LAUNCH_CHECK("k_fy_link");
     hipLaunchKernelGGL(k_fy_resolve, dim3(grid), dim3(256), 0, s, rng->d_j, rng->d_head, rng->d_next, in, out, n);
     AURPPO_LAUNCH_CHECK("k_fy_resolve");
+    rng->seq += 1;
+    return AURPPO_OK;
+}
+
+// Drain the look-ahead and restart the stream at d_state (after seed / set_state wrote it on `s`).
+static int restart_stream(aurppo_rng* rng, hipStream_t s) {
+    AURPPO_HIP_TRY(hipStreamSynchronize(rng->fill_stream));
+    hipLaunchKernelGGL(k_mt_origin, dim3(1), dim3(kFillThreads), 0, s, rng->d_state, rng->d_last, rng->d_ring, rng->d_pos);
+    AURPPO_LAUNCH_CHECK("k_mt_origin");
+    rng->seq = 0;
+    rng->primed_need = 0.0;
     return AURPPO_OK;
 }
 
@@ -400,24 +435,29 @@ extern "C" int aurppo_mt19937_create(aurppo_rng** out, uint32_t seed, int max_n,
     AURPPO_REQUIRE(out, AURPPO_EINVAL, "aurppo_mt19937_create: null out");
     AURPPO_REQUIRE(max_n > 0, AURPPO_ESHAPE, "aurppo_mt19937_create: max_n=%d must be positive", max_n);
     aurppo_rng* r = new aurppo_rng();
+    memset(r, 0, sizeof(*r));
     r->max_n = max_n;
-    r->d_state = nullptr;
-    r->d_j = r->d_head = r->d_next = r->d_tmp = nullptr;
-    r->d_words = nullptr;
-    r->d_meta = nullptr;
-    // worst-case expected draws are < 2n; see permute_once for the per-call sizing
-    r->words_cap = (size_t)(2.2 * (double)max_n + 80.0 * sqrt(2.0 * (double)max_n)) + 16 * kMtN;
+    // 2*need in flight + one maximal fill + slack, rounded to whole blocks
+    const double need = need_words(max_n);
+    r->ring_cap = ((size_t)(4.0 * need) / kMtN + 8) * kMtN;
     const size_t nb = sizeof(int32_t) * (size_t)max_n;
     hipError_t e = hipMalloc(&r->d_state, sizeof(uint32_t) * (kMtN + 1));
+    if (e == hipSuccess) e = hipMalloc(&r->d_last, sizeof(uint32_t) * kMtN);
+    if (e == hipSuccess) e = hipMalloc(&r->d_ring, sizeof(uint32_t) * r->ring_cap);
+    if (e == hipSuccess) e = hipMalloc(&r->d_pos, sizeof(long long) * 4);
     if (e == hipSuccess) e = hipMalloc(&r->d_j, nb);
     if (e == hipSuccess) e = hipMalloc(&r->d_head, nb);
     if (e == hipSuccess) e = hipMalloc(&r->d_next, nb);
     if (e == hipSuccess) e = hipMalloc(&r->d_tmp, nb);
-    if (e == hipSuccess) e = hipMalloc(&r->d_words, sizeof(uint32_t) * r->words_cap);
-    if (e == hipSuccess) e = hipMalloc(&r->d_meta, sizeof(int32_t) * 8);
-    if (e == hipSuccess) e = hipMemsetAsync(r->d_meta, 0, sizeof(int32_t) * 8, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipMalloc(&r->d_meta, sizeof(uint32_t) * (kMtN + 1));
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&r->fill_stream, hipStreamNonBlocking);
+    for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+        e = hipEventCreateWithFlags(&r->ev_fill[k], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&r->ev_acc[k], hipEventDisableTiming);
+    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&r->ev_sync, hipEventDisableTiming);
     if (e != hipSuccess) {
-        aurppo_set_error("aurppo_mt19937_create: hipMalloc failed: %s", hipGetErrorString(e));
+        aurppo_set_error("aurppo_mt19937_create: HIP resource allocation failed: %s", hipGetErrorString(e));
         aurppo_mt19937_destroy(r);
         return AURPPO_EHIP;
     }
@@ -427,35 +467,49 @@ extern "C" int aurppo_mt19937_create(aurppo_rng** out, uint32_t seed, int max_n,
 
 extern "C" int aurppo_mt19937_destroy(aurppo_rng* rng) {
     if (!rng) return AURPPO_OK;
+    if (rng->fill_stream) (void)hipStreamSynchronize(rng->fill_stream);
     (void)hipFree(rng->d_state);
+    (void)hipFree(rng->d_last);
+    (void)hipFree(rng->d_ring);
+    (void)hipFree(rng->d_pos);
     (void)hipFree(rng->d_j);
     (void)hipFree(rng->d_head);
     (void)hipFree(rng->d_next);
     (void)hipFree(rng->d_tmp);
-    (void)hipFree(rng->d_words);
     (void)hipFree(rng->d_meta);
+    for (int k = 0; k < 2; ++k) {
+        if (rng->ev_fill[k]) (void)hipEventDestroy(rng->ev_fill[k]);
+        if (rng->ev_acc[k]) (void)hipEventDestroy(rng->ev_acc[k]);
+    }
+    if (rng->ev_sync) (void)hipEventDestroy(rng->ev_sync);
+    if (rng->fill_stream) (void)hipStreamDestroy(rng->fill_stream);
     delete rng;
     return AURPPO_OK;
 }
 
 extern "C" int aurppo_mt19937_seed(aurppo_rng* rng, uint32_t seed, void* stream) {
     AURPPO_REQUIRE(rng, AURPPO_EINVAL, "aurppo_mt19937_seed: null handle");
+    AURPPO_HIP_TRY(hipStreamSynchronize(rng->fill_stream));   // nothing may still be appending to the ring
     hipLaunchKernelGGL(k_mt_seed, dim3(1), dim3(64), 0, (hipStream_t)stream, rng->d_state, seed);
     AURPPO_LAUNCH_CHECK("k_mt_seed");
-    AURPPO_HIP_TRY(hipMemsetAsync(rng->d_meta, 0, sizeof(int32_t) * 8, (hipStream_t)stream));
-    return AURPPO_OK;
+    return restart_stream(rng, (hipStream_t)stream);
 }
 
 extern "C" int aurppo_mt19937_get_state(aurppo_rng* rng, uint32_t* key_h, int32_t* pos_h, void* stream) {
     AURPPO_REQUIRE(rng && key_h && pos_h, AURPPO_EINVAL, "aurppo_mt19937_get_state: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    AURPPO_HIP_TRY(hipStreamSynchronize(rng->fill_stream));
+    hipLaunchKernelGGL(k_state_at_cursor, dim3(1), dim3(kFillThreads), 0, s, rng->d_state, rng->d_ring,
+                       (long long)rng->ring_cap, rng->d_pos, reinterpret_cast<uint32_t*>(rng->d_meta));
+    AURPPO_LAUNCH_CHECK("k_state_at_cursor");
     uint32_t buf[kMtN + 1];
-    AURPPO_HIP_TRY(hipMemcpyAsync(buf, rng->d_state, sizeof(buf), hipMemcpyDeviceToHost, (hipStream_t)stream));
-    AURPPO_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    long long posv[4];
+    AURPPO_HIP_TRY(hipMemcpyAsync(buf, rng->d_meta, sizeof(buf), hipMemcpyDeviceToHost, s));
+    AURPPO_HIP_TRY(hipMemcpyAsync(posv, rng->d_pos, sizeof(posv), hipMemcpyDeviceToHost, s));
+    AURPPO_HIP_TRY(hipStreamSynchronize(s));
+    AURPPO_REQUIRE(posv[2] == 0, AURPPO_EHIP, "a shuffle ran out of draws (generator state is invalid)");
     for (int i = 0; i < kMtN; ++i) key_h[i] = buf[i];
     *pos_h = (int32_t)buf[kMtN];
-    int32_t meta[4];
-    AURPPO_HIP_TRY(hipMemcpy(meta, rng->d_meta, sizeof(meta), hipMemcpyDeviceToHost));
-    AURPPO_REQUIRE(meta[2] == 0, AURPPO_EHIP, "a shuffle exhausted its word buffer (generator state is invalid)");
     return AURPPO_OK;
 }
 
@@ -463,12 +517,15 @@ extern "C" int aurppo_mt19937_set_state(aurppo_rng* rng, const uint32_t* key_h, 
     AURPPO_REQUIRE(rng && key_h, AURPPO_EINVAL, "aurppo_mt19937_set_state: null pointer");
     AURPPO_REQUIRE(pos_h >= 0 && pos_h <= kMtN, AURPPO_EINVAL, "aurppo_mt19937_set_state: pos=%d out of [0,624]",
                    pos_h);
+    hipStream_t s = (hipStream_t)stream;
     uint32_t buf[kMtN + 1];
     for (int i = 0; i < kMtN; ++i) buf[i] = key_h[i];
     buf[kMtN] = (uint32_t)pos_h;
-    AURPPO_HIP_TRY(hipMemcpyAsync(rng->d_state, buf, sizeof(buf), hipMemcpyHostToDevice, (hipStream_t)stream));
-    AURPPO_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));  // buf is a stack temporary
-    return AURPPO_OK;
+    AURPPO_HIP_TRY(hipStreamSynchronize(rng->fill_stream));
+    AURPPO_HIP_TRY(hipStreamSynchronize(s));   // in-flight shuffles still read the old stream
+    AURPPO_HIP_TRY(hipMemcpyAsync(rng->d_state, buf, sizeof(buf), hipMemcpyHostToDevice, s));
+    AURPPO_HIP_TRY(hipStreamSynchronize(s));   // buf is a stack temporary
+    return restart_stream(rng, s);
 }
 
 extern "C" int aurppo_arange_i32(int32_t* idx, int n, void* stream) {
