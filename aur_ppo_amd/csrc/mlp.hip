@@ -537,35 +537,44 @@ __global__ __launch_bounds__(256, 1) void k_mlp_step(const MlpArgs a) {
 }
 
 // grads[p] = sum over slabs, fixed order (deterministic); block 0 also folds the loss scalars.
-// 64 parameters x 4 slab groups per workgroup: coalesced 256-B rows, 4 independent streams per
-// parameter, combined through LDS in group order.
-__global__ __launch_bounds__(256) void k_mlp_reduce(const float* __restrict__ slabs, const double* __restrict__ loss_part,
-                                                    int n_slabs, int n_params, PpoHyper h, float* __restrict__ grads,
-                                                    float* __restrict__ out_scalars) {
-    __shared__ float s_part[4][64];
+// 64 parameters x 16 slab groups per 1024-thread workgroup: every wave-instruction reads one coalesced
+// 256-B slab row, 16 rows per parameter are in flight at once, groups are combined through LDS in order.
+constexpr int kRedGroups = 16;
+__global__ __launch_bounds__(1024) void k_mlp_reduce(const float* __restrict__ slabs, const double* __restrict__ loss_part,
+                                                     int n_slabs, int n_params, PpoHyper h, float* __restrict__ grads,
+                                                     float* __restrict__ out_scalars) {
+    __shared__ float s_part[kRedGroups][64];
     const int pi = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int p = blockIdx.x * 64 + pi;
     float acc = 0.0f;
     if (p < n_params) {
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
         int b = grp;
-        for (; b + 12 < n_slabs; b += 16) {
+        for (; b + 3 * kRedGroups < n_slabs; b += 4 * kRedGroups) {
             a0 += slabs[(size_t)b * n_params + p];
-            a1 += slabs[(size_t)(b + 4) * n_params + p];
-            a2 += slabs[(size_t)(b + 8) * n_params + p];
-            a3 += slabs[(size_t)(b + 12) * n_params + p];
+            a1 += slabs[(size_t)(b + kRedGroups) * n_params + p];
+            a2 += slabs[(size_t)(b + 2 * kRedGroups) * n_params + p];
+            a3 += slabs[(size_t)(b + 3 * kRedGroups) * n_params + p];
         }
-        for (; b < n_slabs; b += 4) a0 += slabs[(size_t)b * n_params + p];
+        for (; b < n_slabs; b += kRedGroups) a0 += slabs[(size_t)b * n_params + p];
         acc = (a0 + a1) + (a2 + a3);
     }
     s_part[grp][pi] = acc;
     __syncthreads();
-    if (grp == 0 && p < n_params) grads[p] = (s_part[0][pi] + s_part[1][pi]) + (s_part[2][pi] + s_part[3][pi]);
+    if (grp == 0 && p < n_params) {
+        float t = 0.0f;
+#pragma unroll
+        for (int g = 0; g < kRedGroups; ++g) t += s_part[g][pi];
+        grads[p] = t;
+    }
     __shared__ double r[6];
-    if (blockIdx.x == 0 && threadIdx.x < 6) {
+    if (blockIdx.x == 0 && threadIdx.x < 6 * kWave) {
+        // one wave per loss quantity: lanes stride over the workgroups' partials, then a shuffle reduce
+        const int q = threadIdx.x >> 6, l = threadIdx.x & 63;
         double s = 0.0;
-        for (int b = 0; b < n_slabs; ++b) s += loss_part[(size_t)b * 8 + threadIdx.x];
-        r[threadIdx.x] = s;
+        for (int b = l; b < n_slabs; b += kWave) s += loss_part[(size_t)b * 8 + q];
+        s = wave_sum(s);
+        if (l == 0) r[q] = s;
     }
     __syncthreads();
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -667,7 +676,7 @@ static int mlp_step_impl(const float* obs, const float* actions, const float* re
     hipLaunchKernelGGL(k_mlp_step, dim3(grid), dim3(kThreads), lds_bytes(), s, a);
     AURPPO_LAUNCH_CHECK("k_mlp_step");
     if (ev_end) AURPPO_HIP_TRY(hipEventRecord((hipEvent_t)ev_end, s));
-    hipLaunchKernelGGL(k_mlp_reduce, dim3((n_params + 63) / 64), dim3(256), 0, s, a.slabs, a.loss_part, grid, n_params,
+    hipLaunchKernelGGL(k_mlp_reduce, dim3((n_params + 63) / 64), dim3(1024), 0, s, a.slabs, a.loss_part, grid, n_params,
                        a.h, grads, out_scalars);
     AURPPO_LAUNCH_CHECK("k_mlp_reduce");
     return AURPPO_OK;

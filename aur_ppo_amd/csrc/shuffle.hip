@@ -93,11 +93,14 @@ constexpr int kFillThreads = 256;
 // words (at most nblk_max blocks).  Continues from d_last; all bookkeeping is on the device.
 __global__ __launch_bounds__(kFillThreads) void k_mt_fill(uint32_t* __restrict__ last, uint32_t* __restrict__ ring,
                                                           long long ring_cap, long long* __restrict__ posv,
-                                                          long long target, int nblk_max) {
+                                                          long long target, int nblk_max, int cur_slot) {
     __shared__ uint32_t buf[2][kMtN];
     const int tid = threadIdx.x;
     const long long S = posv[0];
-    const long long cur = posv[1];   // may lag a concurrently running consumer: a lower bound, which is safe
+    // Cursor as of the end of a SPECIFIC earlier shuffle (slot 4/5 by parity; slot 1 = live value for the
+    // first fills after a restart).  Reading a fixed shuffle's cursor, not whatever a concurrently running
+    // consumer has published, makes every look-ahead fill produce exactly one shuffle's consumption.
+    const long long cur = posv[cur_slot];
     long long want = target - (S - cur);
     int nblk = want > 0 ? (int)((want + kMtN - 1) / kMtN) : 0;
     if (nblk > nblk_max) nblk = nblk_max;
@@ -105,6 +108,7 @@ __global__ __launch_bounds__(kFillThreads) void k_mt_fill(uint32_t* __restrict__
     for (int k = tid; k < kMtN; k += kFillThreads) buf[0][k] = last[k];
     __syncthreads();
     long long out = S;
+    long long wpos = S % ring_cap;
     int cb = 0;
     for (int b = 0; b < nblk; ++b) {
         const uint32_t* o = buf[cb];
@@ -121,8 +125,14 @@ __global__ __launch_bounds__(kFillThreads) void k_mt_fill(uint32_t* __restrict__
             w[k] = w[k - kMtD] ^ mt_mix(o[k], k == kMtN - 1 ? w[0] : o[k + 1]);
         }
         __syncthreads();
-        for (int k = tid; k < kMtN; k += kFillThreads) ring[(out + k) % ring_cap] = mt_temper(w[k]);
+        for (int k = tid; k < kMtN; k += kFillThreads) {
+            long long at = wpos + k;
+            if (at >= ring_cap) at -= ring_cap;
+            ring[at] = mt_temper(w[k]);
+        }
         out += kMtN;
+        wpos += kMtN;
+        if (wpos >= ring_cap) wpos -= ring_cap;
         cb ^= 1;
     }
     for (int k = tid; k < kMtN; k += kFillThreads) last[k] = buf[cb][k];
@@ -143,6 +153,8 @@ __global__ __launch_bounds__(kFillThreads) void k_mt_origin(const uint32_t* __re
         posv[0] = kMtN - pos;
         posv[1] = 0;
         posv[2] = 0;
+        posv[4] = 0;
+        posv[5] = 0;
     }
 }
 
@@ -173,7 +185,7 @@ constexpr int kAccStep = kAccThreads * kWpt;  // 8192 draws per step
 
 __global__ __launch_bounds__(kAccThreads) void k_fy_accept(const uint32_t* __restrict__ ring, long long ring_cap,
                                                            int32_t* __restrict__ j, int n,
-                                                           long long* __restrict__ posv) {
+                                                           long long* __restrict__ posv, int done_slot) {
     __shared__ int s_wsum[kAccThreads / kWave];
     __shared__ int s_changed[2];
     __shared__ int s_end;
@@ -188,8 +200,13 @@ __global__ __launch_bounds__(kAccThreads) void k_fy_accept(const uint32_t* __res
     uint32_t ynext[kWpt];
     auto fetch = [&](long long cur) {
         const long long b0 = cur + (long long)tid * kWpt;
+        long long r0 = b0 % ring_cap;
 #pragma unroll
-        for (int u = 0; u < kWpt; ++u) ynext[u] = (b0 + u) < avail ? ring[(b0 + u) % ring_cap] : 0u;
+        for (int u = 0; u < kWpt; ++u) {
+            long long at = r0 + u;
+            if (at >= ring_cap) at -= ring_cap;
+            ynext[u] = (b0 + u) < avail ? ring[at] : 0u;
+        }
     };
     fetch(cursor);
     while (i_cur >= 1 && cursor < avail) {
@@ -295,6 +312,7 @@ __global__ __launch_bounds__(kAccThreads) void k_fy_accept(const uint32_t* __res
     }
     if (tid == 0) {
         posv[1] = cursor;
+        posv[done_slot] = cursor;      // this shuffle's final cursor, for the fill two shuffles later
         if (i_cur >= 1) posv[2] = 1;   // ran out of draws before the shuffle finished: sticky error
     }
 }
@@ -368,13 +386,13 @@ static double expected_draws(int n) {
 // sticky error flag instead of producing a wrong permutation.
 static double need_words(int n) { return expected_draws(n) + 12.0 * sqrt(2.0 * (double)n) + 2.0 * kMtN; }
 
-static int enqueue_fill(aurppo_rng* rng, double need, hipStream_t after, int slot) {
+static int enqueue_fill(aurppo_rng* rng, double need, hipStream_t after, int slot, int cur_slot) {
     // inventory target 2*need: one shuffle may be consuming while the next one's draws are produced
     AURPPO_HIP_TRY(hipEventRecord(rng->ev_sync, after));
     AURPPO_HIP_TRY(hipStreamWaitEvent(rng->fill_stream, rng->ev_sync, 0));
     const int nblk_max = (int)(2.0 * need / kMtN) + 2;
     hipLaunchKernelGGL(k_mt_fill, dim3(1), dim3(kFillThreads), 0, rng->fill_stream, rng->d_last, rng->d_ring,
-                       (long long)rng->ring_cap, rng->d_pos, (long long)(2.0 * need), nblk_max);
+                       (long long)rng->ring_cap, rng->d_pos, (long long)(2.0 * need), nblk_max, cur_slot);
     AURPPO_LAUNCH_CHECK("k_mt_fill");
     AURPPO_HIP_TRY(hipEventRecord(rng->ev_fill[slot], rng->fill_stream));
     return AURPPO_OK;
@@ -389,13 +407,14 @@ int permute_once(aurppo_rng* rng, const int32_t* in, int32_t* out, int n, hipStr
     const int slot = (int)(rng->seq & 1);
     if (rng->primed_need < need) {
         // nothing (or too little) in flight for this size: produce this shuffle's draws now
-        int rc = enqueue_fill(rng, need, s, slot);
+        // (ordered after everything on `s`, so the live cursor in slot 1 is final)
+        int rc = enqueue_fill(rng, need, s, slot, 1);
         if (rc != AURPPO_OK) return rc;
         rng->primed_need = need;
     }
     AURPPO_HIP_TRY(hipStreamWaitEvent(s, rng->ev_fill[slot], 0));
     hipLaunchKernelGGL(k_fy_accept, dim3(1), dim3(kAccThreads), 0, s, rng->d_ring, (long long)rng->ring_cap, rng->d_j, n,
-                       rng->d_pos);
+                       rng->d_pos, 4 + slot);
     AURPPO_LAUNCH_CHECK("k_fy_accept");
     // Look-ahead: the NEXT shuffle's draws (assumed the same size) are twisted on the fill stream while
     // this shuffle's accept / link / resolve run here.  It is ordered after the PREVIOUS accept (ev_acc of
@@ -404,7 +423,8 @@ int permute_once(aurppo_rng* rng, const int32_t* in, int32_t* out, int n, hipStr
     {
         const int nblk_max = (int)(2.0 * need / kMtN) + 2;
         hipLaunchKernelGGL(k_mt_fill, dim3(1), dim3(kFillThreads), 0, rng->fill_stream, rng->d_last, rng->d_ring,
-                           (long long)rng->ring_cap, rng->d_pos, (long long)(2.0 * need), nblk_max);
+                           (long long)rng->ring_cap, rng->d_pos, (long long)(2.0 * need), nblk_max,
+                           rng->seq > 0 ? 4 + (slot ^ 1) : 1);   // cursor after the PREVIOUS shuffle (done: waited above)
         AURPPO_LAUNCH_CHECK("k_mt_fill");
         AURPPO_HIP_TRY(hipEventRecord(rng->ev_fill[slot ^ 1], rng->fill_stream));
     }
@@ -444,13 +464,19 @@ extern "C" int aurppo_mt19937_create(aurppo_rng** out, uint32_t seed, int max_n,
     hipError_t e = hipMalloc(&r->d_state, sizeof(uint32_t) * (kMtN + 1));
     if (e == hipSuccess) e = hipMalloc(&r->d_last, sizeof(uint32_t) * kMtN);
     if (e == hipSuccess) e = hipMalloc(&r->d_ring, sizeof(uint32_t) * r->ring_cap);
-    if (e == hipSuccess) e = hipMalloc(&r->d_pos, sizeof(long long) * 4);
+    if (e == hipSuccess) e = hipMalloc(&r->d_pos, sizeof(long long) * 8);
     if (e == hipSuccess) e = hipMalloc(&r->d_j, nb);
     if (e == hipSuccess) e = hipMalloc(&r->d_head, nb);
     if (e == hipSuccess) e = hipMalloc(&r->d_next, nb);
     if (e == hipSuccess) e = hipMalloc(&r->d_tmp, nb);
     if (e == hipSuccess) e = hipMalloc(&r->d_meta, sizeof(uint32_t) * (kMtN + 1));
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&r->fill_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) {
+        // highest priority: the twist is a chain of LDS round trips that needs few issue slots, but needs them
+        // promptly when it shares a CU with MFMA-heavy waves
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        e = hipStreamCreateWithPriority(&r->fill_stream, hipStreamNonBlocking, hi);
+    }
     for (int k = 0; k < 2 && e == hipSuccess; ++k) {
         e = hipEventCreateWithFlags(&r->ev_fill[k], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&r->ev_acc[k], hipEventDisableTiming);

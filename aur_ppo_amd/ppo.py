@@ -221,7 +221,7 @@ class ppo:
             self._perms = self.rng.shuffle_epochs(self.batch_size, self.num_update_epochs, out=out)
             return
         if self._perm_stream is None:
-            self._perm_stream = torch.cuda.Stream(device=self.device)
+            self._perm_stream = torch.cuda.Stream(device=self.device, priority=-1)   # latency-bound kernels: high priority
         self._perm_stream.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self._perm_stream):
             self._perms = self.rng.shuffle_epochs(self.batch_size, self.num_update_epochs, out=out)
