@@ -60,7 +60,7 @@ def load() -> C.CDLL:
     lib.aurppo_clip_adam_f32.argtypes = [vp] * 4 + [C.c_int64, C.c_int64, f64, vp, vp, f64, f64, f64, vp, vp, vp]
     lib.aurppo_mlp_workspace_bytes.argtypes = [i32]
     lib.aurppo_mlp_workspace_bytes.restype = C.c_size_t
-    lib.aurppo_mlp_ppo_step_f32.argtypes = [vp] * 4 + [i32] * 4 + [vp, C.POINTER(i32), i32, vp, f64, f64, f64, i32, i32, vp, vp, vp]
+    lib.aurppo_mlp_ppo_step_f32.argtypes = [vp] * 4 + [i32] * 5 + [vp, C.POINTER(i32), i32, vp, f64, f64, f64, i32, i32, vp, vp, vp]
     lib.aurppo_mlp_ppo_step_ev_f32.argtypes = lib.aurppo_mlp_ppo_step_f32.argtypes + [vp, vp]
     lib.aurppo_clip_workspace_bytes.argtypes = [C.c_int64]
     lib.aurppo_clip_workspace_bytes.restype = C.c_size_t

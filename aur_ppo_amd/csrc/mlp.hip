@@ -69,6 +69,7 @@ struct MlpArgs {
     const double* stats;   // (kStatBlocks, 2) advantage partial sums
     int n_stat_blocks;
     int D, A;
+    int continuous;        // 1: Gaussian head (A action dims), 0: Categorical head (A logits, one action index)
     MlpLayout L;
     PpoHyper h;
 };
@@ -196,6 +197,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_step(const MlpArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int net = wave >> 1, cb = wave & 1;   // net 0 actor / 1 critic; column half of the 64-wide layers
     const int D = a.D, A = a.A;
+    const int AW = a.continuous ? a.A : 1;    // floats per stored action row
     const int out_dim[2] = {A, 1};
 
     // ---- stage weights (once per launch); layer 1 always runs K = 64, so columns >= D stay zero
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_step(const MlpArgs a) {
         for (int e = tid; e < AP; e += kThreads) sB3[n * AP + e] = e < out_dim[n] ? a.params[a.L.b3[n] + e] : 0.0f;
     }
     for (int e = tid; e < AP; e += kThreads) {
-        const float ls = e < A ? a.params[a.L.logstd + e] : 0.0f;
+        const float ls = (a.continuous && e < A) ? a.params[a.L.logstd + e] : 0.0f;
         const float sd = expf(ls);
         sLs[e] = ls;
         sIvar[e] = 1.0f / (sd * sd);
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_step(const MlpArgs a) {
 #pragma unroll
     for (int u = 0; u < APT; ++u) {
         const int e = tid + u * kThreads;
-        a_row[u] = (e % AP) < A ? e / AP : -1;
+        a_row[u] = (e % AP) < AW ? e / AP : -1;
         a_col[u] = e % AP;
     }
     // Sample indices are staged in LDS one tile AHEAD of the rows they address, so the row loads below
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_step(const MlpArgs a) {
 #pragma unroll
         for (int u = 0; u < APT; ++u) {
             const int src = a_row[u] >= 0 ? sidx[a_row[u]] : -1;
-            ar[u] = src >= 0 ? a.actions[(size_t)src * A + a_col[u]] : 0.0f;
+            ar[u] = src >= 0 ? a.actions[(size_t)src * AW + a_col[u]] : 0.0f;
         }
         if (tid < R) {
             p_src = sidx[tid];
@@ -377,22 +379,48 @@ __global__ __launch_bounds__(256, 1) void k_mlp_step(const MlpArgs a) {
                 const float4 rc = sRec[tid];
                 const float* act = sAct + tid * LDO;
                 float logp = 0.0f, ent = 0.0f;
-                for (int k = 0; k < A; ++k) {
-                    const float ls = sLs[k];
-                    const float zk = act[k] - mu[k];
-                    logp += (-(zk * zk) * (0.5f * sIvar[k]) - ls) - 0.9189385332046727f;
-                    ent += (0.5f + 0.9189385332046727f) + ls;
+                if (a.continuous) {
+                    // Normal(mu, exp(logstd)): log-prob and entropy summed over action dims (actor_critic.py:36-43)
+                    for (int k = 0; k < A; ++k) {
+                        const float ls = sLs[k];
+                        const float zk = act[k] - mu[k];
+                        logp += (-(zk * zk) * (0.5f * sIvar[k]) - ls) - 0.9189385332046727f;
+                        ent += (0.5f + 0.9189385332046727f) + ls;
+                    }
+                    const PpoSample t = ppo_sample(logp, rc.x, rc.y, vv[0], rc.w, rc.z, mean, denom, invM, a.h);
+                    l_pg += t.pg; l_vl += t.vl; l_ent += ent; l_okl += t.okl; l_kl += t.kl; l_cf += t.cf;
+                    for (int k = 0; k < A; ++k) {
+                        const float zk = act[k] - mu[k];
+                        const float dmu = t.g_logp * (zk * sIvar[k]);
+                        mu[k] = dmu;
+                        sDls[tid * LDO + k] = t.g_logp * (zk * zk * sIvar[k] - 1.0f) + g_ent;
+                    }
+                    vv[0] = t.g_v;
+                    g_b3c += t.g_v;
+                } else {
+                    // Categorical(logits): log_softmax, log-prob of the stored action, entropy (actor_critic.py:45-50)
+                    float mx = mu[0];
+                    for (int k = 1; k < A; ++k) mx = fmaxf(mx, mu[k]);
+                    float se = 0.0f;
+                    for (int k = 0; k < A; ++k) se += expf(mu[k] - mx);
+                    const float lse = mx + logf(se);
+                    const int ai = (int)act[0];
+                    for (int k = 0; k < A; ++k) {
+                        const float lpk = mu[k] - lse;
+                        ent -= expf(lpk) * lpk;
+                        if (k == ai) logp = lpk;
+                    }
+                    const PpoSample t = ppo_sample(logp, rc.x, rc.y, vv[0], rc.w, rc.z, mean, denom, invM, a.h);
+                    l_pg += t.pg; l_vl += t.vl; l_ent += ent; l_okl += t.okl; l_kl += t.kl; l_cf += t.cf;
+                    // d logp / d z_k = [k == a] - p_k ;  d H / d z_k = -p_k (log p_k + H)
+                    for (int k = 0; k < A; ++k) {
+                        const float lpk = mu[k] - lse;
+                        const float pk = expf(lpk);
+                        mu[k] = t.g_logp * ((k == ai ? 1.0f : 0.0f) - pk) + g_ent * (-pk * (lpk + ent));
+                    }
+                    vv[0] = t.g_v;
+                    g_b3c += t.g_v;
                 }
-                const PpoSample t = ppo_sample(logp, rc.x, rc.y, vv[0], rc.w, rc.z, mean, denom, invM, a.h);
-                l_pg += t.pg; l_vl += t.vl; l_ent += ent; l_okl += t.okl; l_kl += t.kl; l_cf += t.cf;
-                for (int k = 0; k < A; ++k) {
-                    const float zk = act[k] - mu[k];
-                    const float dmu = t.g_logp * (zk * sIvar[k]);
-                    mu[k] = dmu;
-                    sDls[tid * LDO + k] = t.g_logp * (zk * zk * sIvar[k] - 1.0f) + g_ent;
-                }
-                vv[0] = t.g_v;
-                g_b3c += t.g_v;
             } else {
                 for (int k = 0; k < AP; ++k) mu[k] = sDls[tid * LDO + k] = 0.0f;
                 vv[0] = 0.0f;
@@ -506,7 +534,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_step(const MlpArgs a) {
     }
     if (wave == 1) {
         if (lane < A) slab[a.L.b3[0] + lane] = g_head;
-        if (lane >= AP && lane - AP < A) slab[a.L.logstd + lane - AP] = g_head;
+        if (a.continuous && lane >= AP && lane - AP < A) slab[a.L.logstd + lane - AP] = g_head;
     }
     if (wave == 0) {
         float c = lane < R ? g_b3c : 0.0f;
@@ -606,14 +634,15 @@ extern "C" size_t aurppo_mlp_workspace_bytes(int n_params) {
 }
 
 static int mlp_step_impl(const float* obs, const float* actions, const float* rec, const int32_t* idx, int M, int D,
-                         int A, int hidden, const float* params, const int* layout_h, int n_params, float* grads,
+                         int A, int continuous, int hidden, const float* params, const int* layout_h, int n_params, float* grads,
                          double clip, double ent_coef, double vf_coef, int norm_adv, int vloss_mode, float* out_scalars,
                          void* workspace, void* stream, void* ev_begin, void* ev_end) {
     AURPPO_REQUIRE(obs && actions && rec && idx && params && layout_h && grads && out_scalars && workspace, AURPPO_EINVAL,
                    "aurppo_mlp_ppo_step_f32: null pointer");
     AURPPO_REQUIRE(hidden == H, AURPPO_ESHAPE, "aurppo_mlp_ppo_step_f32: hidden_dim=%d (only %d is built)", hidden, H);
     AURPPO_REQUIRE(D >= 2 && D <= H && D % 2 == 0, AURPPO_ESHAPE, "aurppo_mlp_ppo_step_f32: state_dim=%d must be even, 2..%d", D, H);
-    AURPPO_REQUIRE(A >= 1 && A <= AP, AURPPO_ESHAPE, "aurppo_mlp_ppo_step_f32: action_dim=%d must be 1..%d", A, AP);
+    AURPPO_REQUIRE(A >= 1 && A <= AP && (continuous || A >= 2), AURPPO_ESHAPE,
+                   "aurppo_mlp_ppo_step_f32: action_dim=%d must be 1..%d (>= 2 logits for a Categorical head)", A, AP);
     AURPPO_REQUIRE(M > 0 && n_params > 0, AURPPO_ESHAPE, "aurppo_mlp_ppo_step_f32: M=%d n_params=%d", M, n_params);
     AURPPO_REQUIRE(vloss_mode >= 0 && vloss_mode <= 2, AURPPO_EINVAL, "aurppo_mlp_ppo_step_f32: bad vloss_mode %d", vloss_mode);
     AURPPO_REQUIRE(aligned_to(workspace, 16) && aligned_to(rec, 16), AURPPO_EINVAL,
@@ -621,14 +650,15 @@ static int mlp_step_impl(const float* obs, const float* actions, const float* re
     MlpArgs a;
     a.obs = obs; a.actions = actions; a.rec = reinterpret_cast<const float4*>(rec); a.idx = idx; a.params = params;
     a.D = D; a.A = A;
+    a.continuous = continuous ? 1 : 0;
     // layout_h: w1a,b1a,w2a,b2a,w3a,b3a, w1c,b1c,w2c,b2c,w3c,b3c, logstd
     for (int n = 0; n < 2; ++n) {
         a.L.w1[n] = layout_h[6 * n + 0]; a.L.b1[n] = layout_h[6 * n + 1]; a.L.w2[n] = layout_h[6 * n + 2];
         a.L.b2[n] = layout_h[6 * n + 3]; a.L.w3[n] = layout_h[6 * n + 4]; a.L.b3[n] = layout_h[6 * n + 5];
     }
-    a.L.logstd = layout_h[12];
+    a.L.logstd = continuous ? layout_h[12] : 0;
     a.L.n_params = n_params;
-    for (int k = 0; k < 13; ++k)
+    for (int k = 0; k < (continuous ? 13 : 12); ++k)
         AURPPO_REQUIRE(layout_h[k] >= 0 && layout_h[k] < n_params, AURPPO_ESHAPE, "aurppo_mlp_ppo_step_f32: layout[%d]=%d", k, layout_h[k]);
     a.h = make_hyper(M, clip, ent_coef, vf_coef, norm_adv, vloss_mode);
     char* w = reinterpret_cast<char*>(workspace);
@@ -683,18 +713,18 @@ static int mlp_step_impl(const float* obs, const float* actions, const float* re
 }
 
 extern "C" int aurppo_mlp_ppo_step_f32(const float* obs, const float* actions, const float* rec, const int32_t* idx,
-                                       int M, int D, int A, int hidden, const float* params, const int* layout_h,
+                                       int M, int D, int A, int continuous, int hidden, const float* params, const int* layout_h,
                                        int n_params, float* grads, double clip, double ent_coef, double vf_coef,
                                        int norm_adv, int vloss_mode, float* out_scalars, void* workspace, void* stream) {
-    return mlp_step_impl(obs, actions, rec, idx, M, D, A, hidden, params, layout_h, n_params, grads, clip, ent_coef,
+    return mlp_step_impl(obs, actions, rec, idx, M, D, A, continuous, hidden, params, layout_h, n_params, grads, clip, ent_coef,
                          vf_coef, norm_adv, vloss_mode, out_scalars, workspace, stream, nullptr, nullptr);
 }
 
 extern "C" int aurppo_mlp_ppo_step_ev_f32(const float* obs, const float* actions, const float* rec, const int32_t* idx,
-                                          int M, int D, int A, int hidden, const float* params, const int* layout_h,
+                                          int M, int D, int A, int continuous, int hidden, const float* params, const int* layout_h,
                                           int n_params, float* grads, double clip, double ent_coef, double vf_coef,
                                           int norm_adv, int vloss_mode, float* out_scalars, void* workspace,
                                           void* stream, void* ev_begin, void* ev_end) {
-    return mlp_step_impl(obs, actions, rec, idx, M, D, A, hidden, params, layout_h, n_params, grads, clip, ent_coef,
+    return mlp_step_impl(obs, actions, rec, idx, M, D, A, continuous, hidden, params, layout_h, n_params, grads, clip, ent_coef,
                          vf_coef, norm_adv, vloss_mode, out_scalars, workspace, stream, ev_begin, ev_end);
 }

@@ -277,8 +277,9 @@ def mlp_layout(policy, bucket):
     """Float offsets {w1,b1,w2,b2,w3,b3} x {actor, critic} + actor_logstd of ``policy`` (an
     ``actor_critic`` with two hidden layers) inside ``bucket``'s flat buffers, or None if the policy
     does not have the shape K7 is built for."""
-    if not getattr(policy, "continuous", False) or getattr(policy, "num_layers", None) != 2:
+    if getattr(policy, "num_layers", None) != 2 or not hasattr(policy, "continuous"):
         return None
+    cont = bool(policy.continuous)
     if getattr(policy, "hidden_dim", None) != MLP_HIDDEN:
         return None
     off, pos = {}, 0
@@ -290,14 +291,14 @@ def mlp_layout(policy, bucket):
         for net in (policy.actor.net, policy.critic.net):
             for li in (0, 2, 4):
                 seq += [off[id(net[li].weight)], off[id(net[li].bias)]]
-        seq.append(off[id(policy.actor_logstd)])
+        seq.append(off[id(policy.actor_logstd)] if cont else 0)
     except (KeyError, AttributeError, IndexError):
         return None
     D = policy.actor.net[0].weight.shape[1]
     A = policy.actor.net[4].weight.shape[0]
-    if D % 2 or D > MLP_MAX_D or A > MLP_MAX_A or policy.critic.net[4].weight.shape[0] != 1:
+    if D % 2 or D > MLP_MAX_D or A > MLP_MAX_A or policy.critic.net[4].weight.shape[0] != 1 or (not cont and A < 2):
         return None
-    return dict(offsets=seq, n_params=pos, D=D, A=A)
+    return dict(offsets=seq, n_params=pos, D=D, A=A, continuous=cont)
 
 
 def mlp_step_flops(layout, M):
@@ -316,13 +317,14 @@ def mlp_ppo_step(obs, actions, rec, idx, flat_param, layout, flat_grad, clip, en
     ``torch.cuda.Event(enable_timing=True)`` recorded right around the main kernel (bench.py)."""
     lib = _lib_or_raise()
     M, D, A, n = idx.numel(), layout["D"], layout["A"], layout["n_params"]
-    if obs.shape[-1] != D or actions.numel() != obs.shape[0] * A or rec.numel() != obs.shape[0] * 4:
+    cont = layout.get("continuous", True)
+    if obs.shape[-1] != D or actions.numel() != obs.shape[0] * (A if cont else 1) or rec.numel() != obs.shape[0] * 4:
         raise ValueError("mlp_ppo_step: buffer shapes do not match the policy")
     if out_scalars is None:
         out_scalars = torch.empty(N_SCALARS, dtype=torch.float32, device=obs.device)
     ws = _workspace("mlp", lib.aurppo_mlp_workspace_bytes(n), obs.device)
     lay = (C.c_int * 13)(*layout["offsets"])
-    args = (_ptr(obs), _ptr(actions), _ptr(rec), _ptr(idx, torch.int32), M, D, A, MLP_HIDDEN, _ptr(flat_param), lay, n,
+    args = (_ptr(obs), _ptr(actions), _ptr(rec), _ptr(idx, torch.int32), M, D, A, int(cont), MLP_HIDDEN, _ptr(flat_param), lay, n,
             _ptr(flat_grad), float(clip), float(ent_coef), float(vf_coef), int(bool(norm_adv)), int(vloss_mode),
             _ptr(out_scalars), C.c_void_p(ws.data_ptr()), _stream())
     if events is None:

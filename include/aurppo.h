@@ -142,30 +142,31 @@ int aurppo_loss_fwd_bwd_packed_f32(const float* newlogp, const float* newv, cons
 
 /* ---- K7: fused minibatch step for the MLP actor-critic -----------------------------------------
  * One launch sequence replaces, for the reference's MLP policy (actor_critic over two Tanh hidden
- * layers of `hidden` units, Gaussian head with state-independent log-std; src/models/actor_critic.py:
- * 8-51, src/nets/nets.py:19-53), everything between "mb_inds chosen" and "gradients ready":
+ * layers of `hidden` units; Gaussian head with state-independent log-std when `continuous`, Categorical
+ * head over A logits otherwise; src/models/actor_critic.py:8-51, src/nets/nets.py:19-53), everything
+ * between "mb_inds chosen" and "gradients ready":
  *   gathers (src/ppo.py:219-220,225,236,251-257) + evaluate() (src/ppo.py:220) + the loss block
  *   (src/ppo.py:225-264) + loss.backward() (src/ppo.py:267).
- * obs (B,D), actions (B,A) and rec (B,4) = {old_logp, adv, ret, old_v} are the flattened rollout
- * buffers, idx (M,) the minibatch slice of the epoch permutation.  `params` is the flat parameter
+ * obs (B,D), actions ((B,A) floats, or (B,) action indices stored as floats for the Categorical head)
+ * and rec (B,4) = {old_logp, adv, ret, old_v} are the flattened rollout buffers, idx (M,) the minibatch slice of the epoch permutation.  `params` is the flat parameter
  * bucket, layout_h 13 float offsets into it {w1,b1,w2,b2,w3,b3} for the actor, the same for the
- * critic, then actor_logstd (nn.Linear layout: weight[out][in]).  `grads` (n_params floats) is
+ * critic, then actor_logstd (ignored for the Categorical head; nn.Linear layout: weight[out][in]).  `grads` (n_params floats) is
  * OVERWRITTEN with d loss / d params in the same layout; out_scalars as aurppo_loss_fwd_bwd_f32.
  * Built for hidden = 64, even D <= 64, A <= 16; other shapes return AURPPO_ESHAPE (callers then use
  * the per-op path).  workspace: aurppo_mlp_workspace_bytes(n_params) bytes, 16-byte aligned.      */
 size_t aurppo_mlp_workspace_bytes(int n_params);
 int aurppo_mlp_ppo_step_f32(const float* obs, const float* actions, const float* rec,
-                            const int32_t* idx, int M, int D, int A, int hidden, const float* params,
-                            const int* layout_h, int n_params, float* grads, double clip,
-                            double ent_coef, double vf_coef, int norm_adv, int vloss_mode,
+                            const int32_t* idx, int M, int D, int A, int continuous, int hidden,
+                            const float* params, const int* layout_h, int n_params, float* grads,
+                            double clip, double ent_coef, double vf_coef, int norm_adv, int vloss_mode,
                             float* out_scalars, void* workspace, void* stream);
 
 /* Measurement variant: identical work, and the two caller-owned hipEvent_t handles (either may be NULL)
  * are recorded on `stream` immediately before and after the main kernel (k_mlp_step) -- bench.py times
  * the kernel with them (hipEventElapsedTime) without a profiler attached.                           */
 int aurppo_mlp_ppo_step_ev_f32(const float* obs, const float* actions, const float* rec,
-                               const int32_t* idx, int M, int D, int A, int hidden, const float* params,
-                               const int* layout_h, int n_params, float* grads, double clip,
+                               const int32_t* idx, int M, int D, int A, int continuous, int hidden,
+                               const float* params, const int* layout_h, int n_params, float* grads, double clip,
                                double ent_coef, double vf_coef, int norm_adv, int vloss_mode,
                                float* out_scalars, void* workspace, void* stream, void* ev_begin,
                                void* ev_end);

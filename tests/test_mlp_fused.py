@@ -6,21 +6,23 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _setup(T, N, D, A, seed=0):
+def _setup(T, N, D, A, seed=0, cont=True):
     from aur_ppo_amd import hip_ops as H
     from aur_ppo_amd.actor_critic import actor_critic
     from aur_ppo_amd.flat import FlatBucket
     torch.manual_seed(seed)
-    pol = actor_critic(D, (A,), 64, 2, 0.0, True).cuda()
+    pol = actor_critic(D, (A,) if cont else A, 64, 2, 0.0, cont).cuda()
     with torch.no_grad():
-        pol.actor_logstd.copy_(0.3 * torch.randn(1, A))
+        if cont:
+            pol.actor_logstd.copy_(0.3 * torch.randn(1, A))
         for p in pol.parameters():          # make every layer matter (head init is 0.01-scaled)
-            p.add_(0.05 * torch.randn_like(p))
+            p.add_((0.05 if cont else 0.3) * torch.randn_like(p))
     bucket = FlatBucket(pol.parameters())
     B = T * N
     g = torch.Generator(device="cuda").manual_seed(seed)
     obs = torch.randn(B, D, device="cuda", generator=g)
-    act = torch.randn(B, A, device="cuda", generator=g)
+    act = (torch.randn(B, A, device="cuda", generator=g) if cont
+           else torch.randint(0, A, (B,), device="cuda", generator=g).float())
     with torch.no_grad():
         _, lp, _, v = pol.evaluate(obs, act)
     rec = torch.stack([lp + 0.2 * torch.randn(B, device="cuda", generator=g), 2 * torch.randn(B, device="cuda", generator=g),
@@ -76,7 +78,36 @@ def test_fused_step_rejects_unsupported_shapes():
         H.mlp_ppo_step(obs, act, rec, idx, bucket.flat_param, lay, bucket.flat_grad, 0.2, 0.0, 0.5)
     from aur_ppo_amd.actor_critic import actor_critic
     from aur_ppo_amd.flat import FlatBucket
-    disc = actor_critic(4, 2, 64, 2, 0.0, False).cuda()
-    assert H.mlp_layout(disc, FlatBucket(disc.parameters())) is None          # discrete head: per-op path
     wide = actor_critic(64, (6,), 128, 2, 0.0, True).cuda()
     assert H.mlp_layout(wide, FlatBucket(wide.parameters())) is None
+
+
+@pytest.mark.parametrize("T,N,D,A,M", [(8, 64, 4, 2, 200), (16, 64, 64, 16, 1024), (128, 256, 8, 5, 32768)])
+@pytest.mark.parametrize("norm_adv,vmode,ec", [(True, 1, 0.01), (False, 2, 0.05)])
+def test_fused_step_categorical_head_matches_autograd_path(T, N, D, A, M, norm_adv, vmode, ec):
+    """Discrete policy (CartPole-style, BASELINE configs[0]): Categorical log-prob / entropy and their gradients."""
+    H, pol, bucket, obs, act, rec = _setup(T, N, D, A, seed=1, cont=False)
+    idx = torch.randperm(T * N, device="cuda")[:M].int()
+    lay = H.mlp_layout(pol, bucket)
+    assert lay is not None and lay["continuous"] is False and lay["A"] == A
+    mb = H.gather(idx, [obs, act, rec])
+    _, nlp, ent, nv = pol.evaluate(mb[0], mb[1])
+    sc_ref = torch.empty(9, device="cuda")
+    loss = H.ppo_loss_packed(nlp, nv, ent, mb[2], 0.2, ec, 0.5, norm_adv, vmode, sc_ref)
+    bucket.zero_grad()
+    loss.backward()
+    g_ref = bucket.flat_grad[:lay["n_params"]].clone()
+    g_out = torch.full_like(bucket.flat_grad, float("nan"))
+    sc = H.mlp_ppo_step(obs, act, rec, idx, bucket.flat_param, lay, g_out, 0.2, ec, 0.5, norm_adv, vmode)
+    np.testing.assert_allclose(sc.cpu().numpy(), sc_ref.cpu().numpy(), rtol=2e-5, atol=2e-6)
+    g = g_out[:lay["n_params"]]
+    assert torch.isfinite(g).all()
+    gscale = float(g_ref.abs().max())
+    assert float((g - g_ref).abs().max()) <= 2e-5 * gscale + 1e-8
+    off = 0
+    for p_ in bucket.params:      # per tensor: relative to its own scale, with a floor at the global rounding level
+        k = p_.numel()
+        a, b = g[off:off + k], g_ref[off:off + k]
+        s_ = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 5e-5 * s_ + 2e-6 * gscale + 1e-9, (off, float((a - b).abs().max()), s_)
+        off += k
