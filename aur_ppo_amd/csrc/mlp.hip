@@ -564,6 +564,137 @@ __global__ __launch_bounds__(256, 1) void k_mlp_step(const MlpArgs a) {
 #endif
 }
 
+// ---- K8: forward-only sibling of K7 for the rollout step (src/ppo.py:103-108: policy.evaluate(next_obs) under
+// no_grad, then buffer.values / actions / log_probs [step] = ...).  One workgroup per 32-row tile: both nets'
+// forward pass as in K7, then 32 lanes sample the action from caller-supplied noise (a ~ mu + sigma*eps for the
+// Gaussian head, inverse CDF of softmax(logits) at u for the Categorical head), form its log-prob and write
+// action / log-prob / value straight into the rollout buffer rows.  With noise == nullptr only the value is
+// produced (the bootstrap policy.value(next_obs), src/ppo.py:161).
+struct ActArgs {
+    const float* obs;     // (N, D)
+    const float* noise;   // (N, A) standard normal | (N,) uniform [0,1) | nullptr
+    const float* params;
+    float* actions;       // (N, A) | (N,)
+    float* logp;          // (N,)
+    float* value;         // (N,)
+    int N, D, A, continuous;
+    MlpLayout L;
+};
+
+__global__ __launch_bounds__(256, 1) void k_mlp_act(const ActArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* sX = lds;                    // [R][LD]
+    float* sH1 = sX + R * LD;           // [2][R][LD]
+    float* sH2 = sH1 + 2 * R * LD;      // [2][R][LD]
+    float* sW1 = sH2 + 2 * R * LD;      // [2][H][LD]
+    float* sW2 = sW1 + 2 * H * LD;      // [2][H][LD]
+    float* sW3 = sW2 + 2 * H * LD;      // [2][AP][LD]
+    float* sOut = sW3 + 2 * AP * LD;    // [2][R][LDO]
+    float* sB1 = sOut + 2 * R * LDO;    // [2][H]
+    float* sB2 = sB1 + 2 * H;
+    float* sB3 = sB2 + 2 * H;           // [2][AP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int net = wave >> 1, cb = wave & 1;
+    const int D = a.D, A = a.A;
+    const int out_dim[2] = {A, 1};
+    const int row0 = blockIdx.x * R;
+    for (int e = tid; e < R * LD; e += kThreads) sX[e] = 0.0f;
+    for (int e = tid; e < 2 * H * LD; e += kThreads) sW1[e] = 0.0f;
+    __syncthreads();
+    for (int e = tid; e < R * D; e += kThreads) {
+        const int r = e / D, c = e % D;
+        if (row0 + r < a.N) sX[r * LD + c] = a.obs[(size_t)(row0 + r) * D + c];
+    }
+    for (int n = 0; n < 2; ++n) {
+        for (int e = tid; e < H * D; e += kThreads) sW1[(n * H + e / D) * LD + e % D] = a.params[a.L.w1[n] + e];
+        for (int e = tid; e < H * H; e += kThreads) sW2[(n * H + e / H) * LD + e % H] = a.params[a.L.w2[n] + e];
+        for (int e = tid; e < AP * H; e += kThreads) {
+            const int o = e / H, i = e % H;
+            sW3[(n * AP + o) * LD + i] = o < out_dim[n] ? a.params[a.L.w3[n] + o * H + i] : 0.0f;
+        }
+        for (int e = tid; e < H; e += kThreads) {
+            sB1[n * H + e] = a.params[a.L.b1[n] + e];
+            sB2[n * H + e] = a.params[a.L.b2[n] + e];
+        }
+        for (int e = tid; e < AP; e += kThreads) sB3[n * AP + e] = e < out_dim[n] ? a.params[a.L.b3[n] + e] : 0.0f;
+    }
+    __syncthreads();
+    {
+        f32x16 acc = zero16();
+        const float* W = sW1 + (net * H + cb * 32) * LD;
+        mma32<H>(acc, [&](int i, int k) { return sX[i * LD + k]; }, [&](int k, int j) { return W[j * LD + k]; });
+        const int col = cb * 32 + (lane & 31);
+        const float bias = sB1[net * H + col];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sH1[(net * R + acc_row(e, lane)) * LD + col] = tanh_fast(acc[e] + bias);
+    }
+    __syncthreads();
+    {
+        f32x16 acc = zero16();
+        const float* W = sW2 + (net * H + cb * 32) * LD;
+        const float* Hin = sH1 + net * R * LD;
+        mma32<H>(acc, [&](int i, int k) { return Hin[i * LD + k]; }, [&](int k, int j) { return W[j * LD + k]; });
+        const int col = cb * 32 + (lane & 31);
+        const float bias = sB2[net * H + col];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sH2[(net * R + acc_row(e, lane)) * LD + col] = tanh_fast(acc[e] + bias);
+    }
+    __syncthreads();
+    {
+        const float* W = sW3 + net * AP * LD;
+        const float* Hin = sH2 + (net * R + cb * 16) * LD;
+        const f32x4 acc = mma16<H>([&](int i, int k) { return Hin[i * LD + k]; },
+                                   [&](int k, int j) { return W[j * LD + k]; });
+        const int col = lane & 15;
+        const float bias = sB3[net * AP + col];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sOut[(net * R + cb * 16 + 4 * (lane >> 4) + e) * LDO + col] = acc[e] + bias;
+    }
+    __syncthreads();
+    if (tid < R && row0 + tid < a.N) {
+        const int n = row0 + tid;
+        const float* mu = sOut + tid * LDO;
+        a.value[n] = sOut[(R + tid) * LDO];
+        if (a.noise) {
+            if (a.continuous) {
+                float lp = 0.0f;
+                for (int k = 0; k < A; ++k) {
+                    const float ls = a.params[a.L.logstd + k];
+                    const float eps = a.noise[(size_t)n * A + k];
+                    const float act = mu[k] + expf(ls) * eps;
+                    a.actions[(size_t)n * A + k] = act;
+                    const float z = act - mu[k];                       // as evaluate() forms it: (a - mu)
+                    const float sd = expf(ls);
+                    lp += (-(z * z) / (2.0f * (sd * sd)) - ls) - 0.9189385332046727f;
+                }
+                a.logp[n] = lp;
+            } else {
+                float mx = mu[0];
+                for (int k = 1; k < A; ++k) mx = fmaxf(mx, mu[k]);
+                float se = 0.0f;
+                for (int k = 0; k < A; ++k) se += expf(mu[k] - mx);
+                const float lse = mx + logf(se);
+                const float u = a.noise[n];
+                float cdf = 0.0f;
+                int pick = A - 1;
+                for (int k = 0; k < A; ++k) {
+                    cdf += expf(mu[k] - lse);
+                    if (u < cdf) {
+                        pick = k;
+                        break;
+                    }
+                }
+                a.actions[n] = (float)pick;
+                a.logp[n] = mu[pick] - lse;
+            }
+        }
+    }
+}
+
+constexpr size_t act_lds_bytes() {
+    return sizeof(float) * (size_t)(R * LD + 2 * 2 * R * LD + 2 * 2 * H * LD + 2 * AP * LD + 2 * R * LDO + 4 * H + 2 * AP);
+}
+
 // grads[p] = sum over slabs, fixed order (deterministic); block 0 also folds the loss scalars.
 // 64 parameters x 16 slab groups per 1024-thread workgroup: every wave-instruction reads one coalesced
 // 256-B slab row, 16 rows per parameter are in flight at once, groups are combined through LDS in order.
@@ -727,4 +858,35 @@ extern "C" int aurppo_mlp_ppo_step_ev_f32(const float* obs, const float* actions
                                           void* stream, void* ev_begin, void* ev_end) {
     return mlp_step_impl(obs, actions, rec, idx, M, D, A, continuous, hidden, params, layout_h, n_params, grads, clip, ent_coef,
                          vf_coef, norm_adv, vloss_mode, out_scalars, workspace, stream, ev_begin, ev_end);
+}
+
+extern "C" int aurppo_mlp_act_f32(const float* obs, const float* noise, int N, int D, int A, int continuous, int hidden,
+                                  const float* params, const int* layout_h, int n_params, float* actions, float* logp,
+                                  float* value, void* stream) {
+    AURPPO_REQUIRE(obs && params && layout_h && value, AURPPO_EINVAL, "aurppo_mlp_act_f32: null pointer");
+    AURPPO_REQUIRE(!noise || (actions && logp), AURPPO_EINVAL, "aurppo_mlp_act_f32: sampling needs actions and logp outputs");
+    AURPPO_REQUIRE(hidden == H, AURPPO_ESHAPE, "aurppo_mlp_act_f32: hidden_dim=%d (only %d is built)", hidden, H);
+    AURPPO_REQUIRE(D >= 2 && D <= H && D % 2 == 0, AURPPO_ESHAPE, "aurppo_mlp_act_f32: state_dim=%d must be even, 2..%d", D, H);
+    AURPPO_REQUIRE(A >= 1 && A <= AP && (continuous || A >= 2), AURPPO_ESHAPE, "aurppo_mlp_act_f32: action_dim=%d", A);
+    AURPPO_REQUIRE(N > 0 && n_params > 0, AURPPO_ESHAPE, "aurppo_mlp_act_f32: N=%d n_params=%d", N, n_params);
+    ActArgs a;
+    a.obs = obs; a.noise = noise; a.params = params; a.actions = actions; a.logp = logp; a.value = value;
+    a.N = N; a.D = D; a.A = A; a.continuous = continuous ? 1 : 0;
+    for (int n = 0; n < 2; ++n) {
+        a.L.w1[n] = layout_h[6 * n + 0]; a.L.b1[n] = layout_h[6 * n + 1]; a.L.w2[n] = layout_h[6 * n + 2];
+        a.L.b2[n] = layout_h[6 * n + 3]; a.L.w3[n] = layout_h[6 * n + 4]; a.L.b3[n] = layout_h[6 * n + 5];
+    }
+    a.L.logstd = continuous ? layout_h[12] : 0;
+    a.L.n_params = n_params;
+    for (int k = 0; k < (continuous ? 13 : 12); ++k)
+        AURPPO_REQUIRE(layout_h[k] >= 0 && layout_h[k] < n_params, AURPPO_ESHAPE, "aurppo_mlp_act_f32: layout[%d]=%d", k, layout_h[k]);
+    static bool attr_set = false;
+    if (!attr_set) {
+        AURPPO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_act),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)act_lds_bytes()));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_mlp_act, dim3((N + R - 1) / R), dim3(kThreads), act_lds_bytes(), (hipStream_t)stream, a);
+    AURPPO_LAUNCH_CHECK("k_mlp_act");
+    return AURPPO_OK;
 }

@@ -337,6 +337,33 @@ def mlp_ppo_step(obs, actions, rec, idx, flat_param, layout, flat_grad, clip, en
     return out_scalars
 
 
+def mlp_act(obs, noise, flat_param, layout, actions=None, logp=None, value=None):
+    """K8: the rollout step of the MLP actor-critic in one launch.  ``noise``: (N,A) standard-normal draws
+    (Gaussian head) or (N,) uniform draws (Categorical head); None -> value only.  Outputs may be rows of
+    the rollout buffer.  Returns (actions, logp, value)."""
+    lib = _lib_or_raise()
+    N, D, A = obs.shape[0], layout["D"], layout["A"]
+    cont = layout.get("continuous", True)
+    dev = obs.device
+    if value is None:
+        value = torch.empty(N, dtype=torch.float32, device=dev)
+    if noise is not None:
+        if actions is None:
+            actions = torch.empty((N, A) if cont else (N,), dtype=torch.float32, device=dev)
+        if logp is None:
+            logp = torch.empty(N, dtype=torch.float32, device=dev)
+        if noise.numel() != (N * A if cont else N) or actions.numel() != noise.numel() or logp.numel() != N:
+            raise ValueError("mlp_act: noise / output shapes do not match the policy")
+    if obs.shape[-1] != D or value.numel() != N:
+        raise ValueError("mlp_act: obs / value shapes do not match the policy")
+    lay = (C.c_int * 13)(*layout["offsets"])
+    null = C.c_void_p(0)
+    _check(lib.aurppo_mlp_act_f32(_ptr(obs), _ptr(noise) if noise is not None else null, N, D, A, int(cont), MLP_HIDDEN,
+                                  _ptr(flat_param), lay, layout["n_params"], _ptr(actions) if noise is not None else null,
+                                  _ptr(logp) if noise is not None else null, _ptr(value), _stream()), "aurppo_mlp_act_f32")
+    return actions, logp, value
+
+
 # ------------------------------------------------------------------ K6
 def grad_norm_clip_(flat_grads, max_norm, out_norm=None):
     """In-place ``clip_grad_norm_`` over one flat gradient bucket (src/ppo.py:268).  Returns the

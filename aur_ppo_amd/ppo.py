@@ -244,11 +244,21 @@ class ppo:
         raise NotImplementedError("environments are built by aur_ppo_amd.envs.make_vec_env")
 
     def rewards_to_go(self, step, next_obs, global_step, writer):
-        with torch.no_grad():
-            action, logprob, _, value = self.policy.evaluate(next_obs.to(self.device))
-            self.buffer.values[step] = value.flatten()
-        self.buffer.actions[step] = action
-        self.buffer.log_probs[step] = logprob
+        if self._mlp is not None and hasattr(self.ops, "mlp_act"):
+            # K8: forward of both nets, sampling, log-prob and the three buffer row stores in one launch
+            cont = self._mlp["continuous"]
+            noise = (torch.randn((self.num_envs, self._mlp["A"]), device=self.device) if cont
+                     else torch.rand(self.num_envs, device=self.device))
+            action, _, _ = self.ops.mlp_act(next_obs.to(self.device).contiguous(), noise, self.bucket.flat_param, self._mlp,
+                                            self.buffer.actions[step], self.buffer.log_probs[step], self.buffer.values[step])
+            if not cont:
+                action = action.long()
+        else:
+            with torch.no_grad():
+                action, logprob, _, value = self.policy.evaluate(next_obs.to(self.device))
+                self.buffer.values[step] = value.flatten()
+            self.buffer.actions[step] = action
+            self.buffer.log_probs[step] = logprob
         if getattr(self.envs, "device_native", False):
             next_obs, reward, next_done, _, info = self.envs.step(action)
             self.buffer.rewards[step] = reward.view(-1)
@@ -288,7 +298,10 @@ class ppo:
 
     def advantages(self, next_obs, next_done):
         with torch.no_grad():
-            next_value = self.policy.value(next_obs)
+            if self._mlp is not None and hasattr(self.ops, "mlp_act"):
+                _, _, next_value = self.ops.mlp_act(next_obs.contiguous(), None, self.bucket.flat_param, self._mlp)
+            else:
+                next_value = self.policy.value(next_obs)
             if self.gae:
                 returns, advantages = self.run_gae(next_value, next_done)
             else:

@@ -171,6 +171,17 @@ int aurppo_mlp_ppo_step_ev_f32(const float* obs, const float* actions, const flo
                                float* out_scalars, void* workspace, void* stream, void* ev_begin,
                                void* ev_end);
 
+/* ---- K8: rollout step for the MLP actor-critic -----------------------------------------------------
+ * Replaces `action, logprob, _, value = policy.evaluate(next_obs)` under no_grad and the three buffer row
+ * stores that follow it (src/ppo.py:104-108), and with noise == NULL the bootstrap `policy.value(next_obs)`
+ * (src/ppo.py:161).  obs (N,D); noise: (N,A) standard-normal draws for the Gaussian head (a = mu +
+ * exp(logstd)*eps) or (N,) uniform [0,1) draws for the Categorical head (inverse CDF of softmax(logits));
+ * outputs go wherever the caller points them -- normally rows of the rollout buffer: actions (N,A) | (N,),
+ * logp (N,), value (N,).  params / layout_h / n_params / shape limits as aurppo_mlp_ppo_step_f32.       */
+int aurppo_mlp_act_f32(const float* obs, const float* noise, int N, int D, int A, int continuous, int hidden,
+                       const float* params, const int* layout_h, int n_params, float* actions, float* logp,
+                       float* value, void* stream);
+
 /* ---- K6: global-norm gradient clip over one flat bucket -------------------------------------
  * Replaces nn.utils.clip_grad_norm_(params, max_norm) (src/ppo.py:268; src/robot_ppo.py:401):
  * norm = ||g||_2, g *= min(1, max_norm / (norm + 1e-6)).  out_norm: 1 float (device), the

@@ -111,3 +111,43 @@ def test_fused_step_categorical_head_matches_autograd_path(T, N, D, A, M, norm_a
         s_ = float(b.abs().max())
         assert float((a - b).abs().max()) <= 5e-5 * s_ + 2e-6 * gscale + 1e-9, (off, float((a - b).abs().max()), s_)
         off += k
+
+
+# ---------------------------------------------------------------------------------- K8: rollout step
+@pytest.mark.parametrize("N,D,A,cont", [(4096, 64, 6, True), (77, 4, 2, False), (256, 16, 16, True), (33, 8, 5, False), (1, 64, 1, True)])
+def test_act_kernel_matches_torch_formulas(N, D, A, cont):
+    H, pol, bucket, _obs, _act, _rec = _setup(2, 32, D, A, seed=2, cont=cont)
+    lay = H.mlp_layout(pol, bucket)
+    g = torch.Generator(device="cuda").manual_seed(N)
+    obs = torch.randn(N, D, device="cuda", generator=g)
+    with torch.no_grad():
+        v_ref = pol.value(obs)
+        if cont:
+            noise = torch.randn(N, A, device="cuda", generator=g)
+            mean = pol.actor(obs)
+            std = pol.actor_logstd.exp().expand_as(mean)
+            a_ref = mean + std * noise
+            _, lp_ref, _, _ = pol.evaluate(obs, a_ref)
+        else:
+            noise = torch.rand(N, device="cuda", generator=g)
+            logp_all = torch.log_softmax(pol.actor(obs), -1)
+            cdf = logp_all.exp().cumsum(-1)
+            a_ref = (noise.unsqueeze(1) >= cdf).sum(1).clamp(max=A - 1)
+            lp_ref = logp_all.gather(1, a_ref.unsqueeze(1)).squeeze(1)
+    actions, logp, value = H.mlp_act(obs, noise, bucket.flat_param, lay)
+    torch.testing.assert_close(value, v_ref, rtol=1e-5, atol=2e-6)
+    if cont:
+        torch.testing.assert_close(actions, a_ref, rtol=1e-5, atol=2e-6)
+        torch.testing.assert_close(logp, lp_ref, rtol=1e-5, atol=2e-5)
+    else:
+        same = actions.long() == a_ref
+        assert same.float().mean() > 0.99      # a draw within rounding of a CDF edge may fall either side
+        torch.testing.assert_close(logp[same], lp_ref[same], rtol=1e-5, atol=2e-6)
+    # value-only mode (the bootstrap) and writing straight into buffer rows
+    _, _, v2 = H.mlp_act(obs, None, bucket.flat_param, lay)
+    assert torch.equal(v2, value)
+    buf_a = torch.zeros((3, N, A) if cont else (3, N), device="cuda")
+    buf_lp, buf_v = torch.zeros(3, N, device="cuda"), torch.zeros(3, N, device="cuda")
+    H.mlp_act(obs, noise, bucket.flat_param, lay, buf_a[1], buf_lp[1], buf_v[1])
+    assert torch.equal(buf_a[1], actions) and torch.equal(buf_lp[1], logp) and torch.equal(buf_v[1], value)
+    assert float(buf_a[0].abs().sum() + buf_a[2].abs().sum() + buf_v[0].abs().sum() + buf_lp[2].abs().sum()) == 0.0
