@@ -129,6 +129,7 @@ class ppo:
         self._perms = None
         self._perm_bufs = None
         self._perm_flip = 0
+        self._last_perms = None
         n_steps = self.num_update_epochs * ((self.batch_size + self.minibatch_size - 1) // self.minibatch_size)
         self._scalars = torch.zeros((n_steps, ops.N_SCALARS), device=self.device)
         self._norms = torch.zeros(n_steps, device=self.device)
@@ -320,6 +321,7 @@ class ppo:
         self._adopt_lr()
         packed = self._rec_of is not None and self._rec_of[0] is returns and self._rec_of[1] is advantages
         perms = self._take_perms()
+        self._last_perms = perms        # complete and valid: what the probes below may index with
         graphable = self.use_graph and packed and self.target_kl is None and self._probe is None
         if not graphable:
             return self._update_body(returns, advantages, perms, packed)
@@ -394,7 +396,7 @@ class ppo:
         same sources) with ``probe.begin()/end()`` around the C call.  bench.py uses it to time K3 with
         HIP events inside the timed region when the update itself runs as a hipGraph (events cannot be
         read back from inside a captured graph)."""
-        perms = self._perm_static if self._perm_static is not None else self._perm_bufs[self._perm_flip ^ 1]
+        perms = self._perm_static if self._perm_static is not None else self._last_perms
         srcs = [self.buffer.states.reshape((-1,) + self.buffer.observation_shape),
                 self.buffer.actions.reshape((-1,) + self.buffer.action_shape), self._rec]
         if self._probe_outs is None:
@@ -404,7 +406,7 @@ class ppo:
     def probe_mlp_step(self, events):
         """One stand-alone K7 launch on the update's own first minibatch (gradients go to a scratch
         bucket), with ``events`` recorded right around ``k_mlp_step`` inside the library call."""
-        perms = self._perm_static if self._perm_static is not None else self._perm_bufs[self._perm_flip ^ 1]
+        perms = self._perm_static if self._perm_static is not None else self._last_perms
         if self._probe_mlp_outs is None:
             self._probe_mlp_outs = [torch.empty_like(self.bucket.flat_grad), torch.empty(self.ops.N_SCALARS, device=self.device)]
         vmode = self.ops.VLOSS_CLIPPED if self.clip_vloss else self.ops.VLOSS_OLDVALUES
