@@ -23,8 +23,6 @@
 // 157 TFLOP/s fp32 MFMA peak; HBM traffic 39 MB (5 us).
 #include <stdlib.h>
 
-#include "ppo_math.h"
-
 // Diagnostic build only (tools/mlp_stamps.sh): -DAURPPO_MLP_STAMPS adds s_memtime stamps per phase and
 // dumps wave 0's cycle shares to the tail of the workspace.  The product library is built without it.
 #ifdef AURPPO_MLP_STAMPS
@@ -38,124 +36,28 @@
 #define STAMP(k) do { } while (0)
 #endif
 
+#include "mlp_common.h"
+
+using namespace aurppo_mlp;
+
 namespace {
 
-constexpr int H = 64;        // hidden width
-constexpr int R = 32;        // rows per tile
-constexpr int LD = H + 1;    // LDS row stride of every 64-wide matrix (odd: conflict-free both ways)
-constexpr int AP = 16;       // padded head width (action_dim <= 16)
-constexpr int LDO = AP + 1;
-constexpr int kThreads = 256;
-constexpr int kMaxGrid = 256;
-constexpr int kStatBlocks = 256;
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-struct MlpLayout {  // float offsets into the flat parameter / gradient bucket
-    int w1[2], b1[2], w2[2], b2[2], w3[2], b3[2];  // [0] actor, [1] critic
-    int logstd;
-    int n_params;
-};
-
-struct MlpArgs {
-    const float* obs;      // (B, D) rollout observations (flattened buffer)
-    const float* actions;  // (B, A)
-    const float4* rec;     // (B, 4) {old_logp, adv, ret, old_v}
-    const int32_t* idx;    // (M,) minibatch permutation slice
-    const float* params;   // flat bucket
-    float* slabs;          // (grid, n_params) per-workgroup gradient slabs
-    double* loss_part;     // (grid, 8)
-    unsigned long long* stamps;  // diagnostic build: (grid, 16) cycle counters
-    const double* stats;   // (kStatBlocks, 2) advantage partial sums
-    int n_stat_blocks;
-    int D, A;
-    int continuous;        // 1: Gaussian head (A action dims), 0: Categorical head (A logits, one action index)
-    MlpLayout L;
-    PpoHyper h;
-};
-
-// accumulator element e of a 32x32 MFMA block: (row, col) owned by this lane
-__device__ __forceinline__ int acc_row(int e, int lane) { return (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5); }
-
-// acc += A(32 x K) * B(K x 32); a_at(i,k) / b_at(k,j) fetch operand elements (LDS reads).
-// K is a compile-time constant: the chain is fully unrolled in chunks of 8 MFMAs whose 16 operand
-// reads are issued one chunk ahead -- with one wave per SIMD nobody else hides the LDS latency.
-template <int K, class FA, class FB>
-__device__ __forceinline__ void mma32(f32x16& acc, FA a_at, FB b_at) {
-    static_assert(K % 16 == 0, "K must be a multiple of 16");
-    const int lane = threadIdx.x & 63;
-    const int ij = lane & 31, kk = lane >> 5;
-    float av[2][8], bv[2][8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        av[0][u] = a_at(ij, 2 * u + kk);
-        bv[0][u] = b_at(2 * u + kk, ij);
-    }
-#pragma unroll
-    for (int c = 0; c < K / 16; ++c) {
-        if (c + 1 < K / 16) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                av[(c + 1) & 1][u] = a_at(ij, 16 * (c + 1) + 2 * u + kk);
-                bv[(c + 1) & 1][u] = b_at(16 * (c + 1) + 2 * u + kk, ij);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c & 1][u], bv[c & 1][u], acc, 0, 0, 0);
-    }
-}
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-// 16x16 output tile: acc += A(16 x K) * B(K x 16) on v_mfma_f32_16x16x4_f32 (lane l: A[l&15][l>>4],
-// B[l>>4][l&15]; C: col = l&15, row = 4*(l>>4) + reg).  Two interleaved accumulators hide the 40-cycle
-// dependent latency behind the 32-cycle issue interval; operands are read one 8-MFMA chunk ahead.
-template <int K, class FA, class FB>
-__device__ __forceinline__ f32x4 mma16(FA a_at, FB b_at) {
-    static_assert(K % 32 == 0, "K must be a multiple of 32");
-    const int lane = threadIdx.x & 63;
-    const int ij = lane & 15, kk = lane >> 4;
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    float av[2][8], bv[2][8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        av[0][u] = a_at(ij, 4 * u + kk);
-        bv[0][u] = b_at(4 * u + kk, ij);
-    }
-#pragma unroll
-    for (int c = 0; c < K / 32; ++c) {
-        if (c + 1 < K / 32) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                av[(c + 1) & 1][u] = a_at(ij, 32 * (c + 1) + 4 * u + kk);
-                bv[(c + 1) & 1][u] = b_at(32 * (c + 1) + 4 * u + kk, ij);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u += 2) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c & 1][u], bv[c & 1][u], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c & 1][u + 1], bv[c & 1][u + 1], acc1, 0, 0, 0);
-        }
-    }
-    return acc0 + acc1;
-}
-
-// tanh(x) = 1 - 2 / (e^{2x} + 1): v_exp + v_rcp, absolute error ~1e-7 everywhere (saturates cleanly)
-__device__ __forceinline__ float tanh_fast(float x) {
-    const float e = __expf(2.0f * x);
-    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
-}
-
-__device__ __forceinline__ f32x16 zero16() {
-    f32x16 z;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) z[e] = 0.0f;
-    return z;
-}
-
+// Also lays out W1 of both nets in the B-operand order of k_mlp_step2's layer-1 MFMA chain (w1op != nullptr):
+// w1op[(w * 32 + m) * 64 + lane] = W1[net = w >> 1][(w & 1) * 32 + (lane & 31)][2m + (lane >> 5)], zero beyond D, so
+// that wave w reads its slice with 32 fully coalesced loads per tile instead of holding it in registers.
 __global__ __launch_bounds__(256) void k_adv_stats_idx(const float4* __restrict__ rec, const int32_t* __restrict__ idx,
-                                                       int M, double (*__restrict__ stats)[2]) {
+                                                       int M, double (*__restrict__ stats)[2], const float* __restrict__ params,
+                                                       int w1_actor, int w1_critic, int D, float* __restrict__ w1op,
+                                                       unsigned* __restrict__ tile_counter) {
     __shared__ double sc[2][kThreads / kWave];
+    if (w1op) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) *tile_counter = 0u;
+        for (int e = blockIdx.x * kThreads + threadIdx.x; e < 4 * 32 * 64; e += gridDim.x * kThreads) {
+            const int lane = e & 63, m = (e >> 6) & 31, w = e >> 11;
+            const int row = (w & 1) * 32 + (lane & 31), k = 2 * m + (lane >> 5);
+            w1op[e] = k < D ? params[((w >> 1) ? w1_critic : w1_actor) + row * D + k] : 0.0f;
+        }
+    }
     double s = 0.0, q = 0.0;
     for (int i = blockIdx.x * kThreads + threadIdx.x; i < M; i += gridDim.x * kThreads) {
         const double a = (double)rec[idx[i]].y;
@@ -761,7 +663,7 @@ constexpr size_t lds_bytes() {
 
 extern "C" size_t aurppo_mlp_workspace_bytes(int n_params) {
     return sizeof(double) * 2 * kStatBlocks + sizeof(double) * 8 * kMaxGrid + sizeof(float) * (size_t)kMaxGrid * (size_t)n_params + 64 +
-           sizeof(unsigned long long) * 16 * kMaxGrid;
+           sizeof(unsigned long long) * 32 * kMaxGrid + sizeof(float) * 4 * 32 * 64 + 64;
 }
 
 static int mlp_step_impl(const float* obs, const float* actions, const float* rec, const int32_t* idx, int M, int D,
@@ -803,17 +705,27 @@ static int mlp_step_impl(const float* obs, const float* actions, const float* re
     int sb = (M + kThreads * 4 - 1) / (kThreads * 4);
     if (sb > kStatBlocks) sb = kStatBlocks;
     a.n_stat_blocks = sb;
+    const char* ve = getenv("AURPPO_MLP_VARIANT");   // read per call so that a test can run both variants in one process
+    const int variant = (ve && *ve == '1') ? 1 : 2;
+    a.w1op = reinterpret_cast<float*>(a.stamps + 32 * kMaxGrid);
+    a.tile_counter = reinterpret_cast<unsigned*>(a.w1op + 4 * 32 * 64);
+    {
+        const char* se = getenv("AURPPO_MLP_SKEW");   // experiments only
+        a.skew = (se && *se >= '0' && *se <= '7') ? *se - '0' : 3;
+    }
     hipLaunchKernelGGL(k_adv_stats_idx, dim3(sb), dim3(kThreads), 0, s, a.rec, idx, M,
-                       reinterpret_cast<double (*)[2]>(stats));
+                       reinterpret_cast<double (*)[2]>(stats), params, a.L.w1[0], a.L.w1[1], D, variant == 2 ? a.w1op : nullptr,
+                       a.tile_counter);
     AURPPO_LAUNCH_CHECK("k_adv_stats_idx");
     const int n_tiles = (M + R - 1) / R;
-    // One persistent workgroup per CU, minus one CU per XCD (AURPPO_MLP_SPARE_CUS, default 8): workgroups
-    // are dealt round-robin over the 8 XCDs, so a grid of 248 leaves every XCD one free CU for the
-    // single-workgroup shuffle kernels that run concurrently on the side stream.  A statically strided
-    // persistent kernel runs at the pace of its slowest workgroup, and sharing a CU with the 16-wave
-    // k_fy_accept stretched 92 % of the launches (rocprof in-situ: mean 263 us, p90 380 us with spare = 0, 1
-    // or 2; mean 214 us, p90 224 us with 8).
-    static int cus = 0, spare = 8;
+    // One persistent workgroup per CU, minus one CU per XCD (AURPPO_MLP_SPARE_CUS, default 8; workgroups are dealt
+    // round-robin over the 8 XCDs): the single-workgroup shuffle kernels of the side stream then have a CU of
+    // their own.  The one-set kernel strides statically over the tiles and runs at the pace of its slowest
+    // workgroup: sharing a CU with the 16-wave k_fy_accept stretched 92 % of its launches (rocprof in-situ: mean
+    // 263 us with 0-2 spare CUs, 214 us with 8).  The two-set kernel hands tiles out dynamically, but it fills a
+    // CU's register file, so a workgroup whose CU is taken starts late; 8 spare CUs measured 3.86-3.93 ms per
+    // update against 4.09-4.10 ms with none.
+    static int cus = 0, spare_env = -1;
     if (!cus) {
         int dev = 0;
         hipDeviceProp_t prop;
@@ -821,12 +733,15 @@ static int mlp_step_impl(const float* obs, const float* actions, const float* re
         AURPPO_HIP_TRY(hipGetDeviceProperties(&prop, dev));
         cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : kMaxGrid;
         const char* e = getenv("AURPPO_MLP_SPARE_CUS");
-        if (e && *e) spare = atoi(e);
+        if (e && *e) spare_env = atoi(e);
     }
+    const int spare = spare_env >= 0 ? spare_env : 8;
+    // AURPPO_MLP_VARIANT: 2 (default) = two tile sets per workgroup (mlp2.hip), 1 = one tile set (k_mlp_step below)
     int grid = cus - spare;
     if (grid > kMaxGrid) grid = kMaxGrid;
     if (grid < 1) grid = 1;
-    if (grid > n_tiles) grid = n_tiles;
+    const int tiles_per_wg = variant == 2 ? 2 : 1;
+    if (grid > (n_tiles + tiles_per_wg - 1) / tiles_per_wg) grid = (n_tiles + tiles_per_wg - 1) / tiles_per_wg;
     static bool attr_set = false;
     if (!attr_set) {
         AURPPO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_step),
@@ -834,8 +749,13 @@ static int mlp_step_impl(const float* obs, const float* actions, const float* re
         attr_set = true;
     }
     if (ev_begin) AURPPO_HIP_TRY(hipEventRecord((hipEvent_t)ev_begin, s));
-    hipLaunchKernelGGL(k_mlp_step, dim3(grid), dim3(kThreads), lds_bytes(), s, a);
-    AURPPO_LAUNCH_CHECK("k_mlp_step");
+    if (variant == 2) {
+        const int rc = launch_mlp_step2(a, grid, s);
+        if (rc != AURPPO_OK) return rc;
+    } else {
+        hipLaunchKernelGGL(k_mlp_step, dim3(grid), dim3(kThreads), lds_bytes(), s, a);
+        AURPPO_LAUNCH_CHECK("k_mlp_step");
+    }
     if (ev_end) AURPPO_HIP_TRY(hipEventRecord((hipEvent_t)ev_end, s));
     hipLaunchKernelGGL(k_mlp_reduce, dim3((n_params + 63) / 64), dim3(1024), 0, s, a.slabs, a.loss_part, grid, n_params,
                        a.h, grads, out_scalars);

@@ -1,0 +1,141 @@
+// Shared pieces of the fused MLP kernels (K7 k_mlp_step / k_mlp_step2, K8 k_mlp_act): tile constants, the
+// argument block, the fp32 MFMA micro-kernels and the tanh used by every variant.
+#pragma once
+#include "ppo_math.h"
+
+namespace aurppo_mlp {
+
+constexpr int H = 64;        // hidden width
+constexpr int R = 32;        // rows per tile
+constexpr int LD = H + 1;    // LDS row stride of every 64-wide matrix (odd: conflict-free both ways)
+constexpr int AP = 16;       // padded head width (action_dim <= 16)
+constexpr int LDO = AP + 1;
+constexpr int kThreads = 256;
+constexpr int kMaxGrid = 256;
+constexpr int kStatBlocks = 256;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct MlpLayout {  // float offsets into the flat parameter / gradient bucket
+    int w1[2], b1[2], w2[2], b2[2], w3[2], b3[2];  // [0] actor, [1] critic
+    int logstd;
+    int n_params;
+};
+
+struct MlpArgs {
+    const float* obs;      // (B, D) rollout observations (flattened buffer)
+    const float* actions;  // (B, A)
+    const float4* rec;     // (B, 4) {old_logp, adv, ret, old_v}
+    const int32_t* idx;    // (M,) minibatch permutation slice
+    const float* params;   // flat bucket
+    float* slabs;          // (grid, n_params) per-workgroup gradient slabs
+    double* loss_part;     // (grid, 8)
+    unsigned long long* stamps;  // diagnostic build: (grid, 16) cycle counters
+    int skew;              // two-set kernel: phase offset between the sets (AURPPO_MLP_SKEW, default 3)
+    unsigned* tile_counter;  // two-set kernel: next tile to hand out (zeroed by k_adv_stats_idx)
+    float* w1op;           // two-set kernel: W1 slices in MFMA B-operand order, [4 waves][32 k-steps][64 lanes]
+    const double* stats;   // (kStatBlocks, 2) advantage partial sums
+    int n_stat_blocks;
+    int D, A;
+    int continuous;        // 1: Gaussian head (A action dims), 0: Categorical head (A logits, one action index)
+    MlpLayout L;
+    PpoHyper h;
+};
+
+// accumulator element e of a 32x32 MFMA block: (row, col) owned by this lane
+__device__ __forceinline__ int acc_row(int e, int lane) { return (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5); }
+
+// acc += A(32 x K) * B(K x 32); a_at(i,k) / b_at(k,j) fetch operand elements (LDS reads).
+// K is a compile-time constant: the chain is fully unrolled in chunks of CH MFMAs whose 2*CH operand
+// reads are issued one chunk ahead -- with one wave per SIMD nobody else hides the LDS latency (CH = 8);
+// the two-set kernel runs two waves per SIMD and has half the registers, so it uses CH = 4.
+template <int K, int CH = 8, bool FENCE = false, class FA, class FB>
+__device__ __forceinline__ void mma32(f32x16& acc, FA a_at, FB b_at, int lane) {
+    static_assert(K % (2 * CH) == 0, "K must be a multiple of the chunk depth");
+    const int ij = lane & 31, kk = lane >> 5;
+    float av[2][CH], bv[2][CH];
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+        av[0][u] = a_at(ij, 2 * u + kk);
+        bv[0][u] = b_at(2 * u + kk, ij);
+    }
+#pragma unroll
+    for (int c = 0; c < K / (2 * CH); ++c) {
+        if (c + 1 < K / (2 * CH)) {
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                av[(c + 1) & 1][u] = a_at(ij, 2 * CH * (c + 1) + 2 * u + kk);
+                bv[(c + 1) & 1][u] = b_at(2 * CH * (c + 1) + 2 * u + kk, ij);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < CH; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c & 1][u], bv[c & 1][u], acc, 0, 0, 0);
+        // FENCE pins the pipeline depth to what is written here: without it the scheduler hoists every operand
+        // read of the unrolled chain to the top, which costs ~2K registers the two-set kernel does not have.
+        if (FENCE) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int K, int CH = 8, class FA, class FB>
+__device__ __forceinline__ void mma32(f32x16& acc, FA a_at, FB b_at) {
+    mma32<K, CH, false>(acc, a_at, b_at, (int)(threadIdx.x & 63));
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// 16x16 output tile: acc += A(16 x K) * B(K x 16) on v_mfma_f32_16x16x4_f32 (lane l: A[l&15][l>>4],
+// B[l>>4][l&15]; C: col = l&15, row = 4*(l>>4) + reg).  Two interleaved accumulators hide the 40-cycle
+// dependent latency behind the 32-cycle issue interval; operands are read one 8-MFMA chunk ahead.
+template <int K, bool FENCE = false, class FA, class FB>
+__device__ __forceinline__ f32x4 mma16(FA a_at, FB b_at, int lane) {
+    static_assert(K % 32 == 0, "K must be a multiple of 32");
+    const int ij = lane & 15, kk = lane >> 4;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    float av[2][8], bv[2][8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        av[0][u] = a_at(ij, 4 * u + kk);
+        bv[0][u] = b_at(4 * u + kk, ij);
+    }
+#pragma unroll
+    for (int c = 0; c < K / 32; ++c) {
+        if (c + 1 < K / 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                av[(c + 1) & 1][u] = a_at(ij, 32 * (c + 1) + 4 * u + kk);
+                bv[(c + 1) & 1][u] = b_at(32 * (c + 1) + 4 * u + kk, ij);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c & 1][u], bv[c & 1][u], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c & 1][u + 1], bv[c & 1][u + 1], acc1, 0, 0, 0);
+        }
+        if (FENCE) __builtin_amdgcn_sched_barrier(0);
+    }
+    return acc0 + acc1;
+}
+
+template <int K, class FA, class FB>
+__device__ __forceinline__ f32x4 mma16(FA a_at, FB b_at) {
+    return mma16<K, false>(a_at, b_at, (int)(threadIdx.x & 63));
+}
+
+// tanh(x) = 1 - 2 / (e^{2x} + 1): v_exp + v_rcp, absolute error ~1e-7 everywhere (saturates cleanly)
+__device__ __forceinline__ float tanh_fast(float x) {
+    const float e = __expf(2.0f * x);
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) z[e] = 0.0f;
+    return z;
+}
+
+// mlp2.hip: the two-tile-set variant of K7 (8 waves per workgroup); same arguments, same slab / loss_part outputs.
+size_t mlp_step2_lds_bytes();
+int launch_mlp_step2(const MlpArgs& a, int grid, hipStream_t s);
+
+}  // namespace aurppo_mlp

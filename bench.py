@@ -225,12 +225,12 @@ def main():
         ms = float(np.mean([b.elapsed_time(e) for b, e in mlp_events]))
         flops = H.mlp_step_flops(agent._mlp, M)
         ach = flops / (ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": "k_mlp_step (K7: gather + actor/critic forward + PPO loss + backward)",
+        roofline = {"bound": "mfma", "kernel": ("k_mlp_step" if os.environ.get("AURPPO_MLP_VARIANT") == "1" else "k_mlp_step2") + " (K7: gather + actor/critic forward + PPO loss + backward)",
                     "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": pmc("mlp_pmc.json"),
                     "flops_per_launch": flops, "avg_launch_us": round(ms * 1e3, 2), "launches_timed": len(mlp_events),
                     "algorithmic_hbm_bytes_per_launch": M * (4 * (Dm + A + 4) + 4),
-                    "how": "hipEvent pair recorded inside the library around k_mlp_step, one extra stand-alone "
+                    "how": "hipEvent pair recorded inside the library around the K7 kernel, one extra stand-alone "
                            "launch every 4th step on the update's own minibatch (the update itself is a hipGraph)"}
     elif probe.pairs:
         gather_bytes = M * (8 * Dm + 8 * A + 36)          # idx + 6 streams read + written

@@ -31,10 +31,17 @@ def _setup(T, N, D, A, seed=0, cont=True):
     return H, pol, bucket, obs, act, rec
 
 
+@pytest.fixture(params=["2", "1"], ids=["two-set", "one-set"])
+def variant(request, monkeypatch):
+    """Both builds of K7: k_mlp_step2 (default) and k_mlp_step (AURPPO_MLP_VARIANT=1)."""
+    monkeypatch.setenv("AURPPO_MLP_VARIANT", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("T,N,D,A,M", [(8, 64, 64, 6, 256), (16, 64, 64, 6, 1000), (4, 32, 4, 1, 77), (8, 32, 32, 16, 128),
-                                         (128, 1024, 64, 6, 131072)])
+                                         (8, 32, 6, 3, 100), (8, 64, 10, 9, 31), (128, 1024, 64, 6, 131072)])
 @pytest.mark.parametrize("norm_adv,vmode", [(True, 1), (False, 2), (True, 0)])
-def test_fused_step_matches_autograd_path(T, N, D, A, M, norm_adv, vmode):
+def test_fused_step_matches_autograd_path(T, N, D, A, M, norm_adv, vmode, variant):
     H, pol, bucket, obs, act, rec = _setup(T, N, D, A)
     B = T * N
     idx = torch.randperm(B, device="cuda")[:M].int()
@@ -82,9 +89,9 @@ def test_fused_step_rejects_unsupported_shapes():
     assert H.mlp_layout(wide, FlatBucket(wide.parameters())) is None
 
 
-@pytest.mark.parametrize("T,N,D,A,M", [(8, 64, 4, 2, 200), (16, 64, 64, 16, 1024), (128, 256, 8, 5, 32768)])
+@pytest.mark.parametrize("T,N,D,A,M", [(8, 64, 4, 2, 200), (16, 64, 64, 16, 1024), (8, 64, 6, 11, 333), (128, 256, 8, 5, 32768)])
 @pytest.mark.parametrize("norm_adv,vmode,ec", [(True, 1, 0.01), (False, 2, 0.05)])
-def test_fused_step_categorical_head_matches_autograd_path(T, N, D, A, M, norm_adv, vmode, ec):
+def test_fused_step_categorical_head_matches_autograd_path(T, N, D, A, M, norm_adv, vmode, ec, variant):
     """Discrete policy (CartPole-style, BASELINE configs[0]): Categorical log-prob / entropy and their gradients."""
     H, pol, bucket, obs, act, rec = _setup(T, N, D, A, seed=1, cont=False)
     idx = torch.randperm(T * N, device="cuda")[:M].int()

@@ -8,10 +8,13 @@ python3 - <<PY
 import csv, glob, json, statistics as st
 f = glob.glob("gpurun_out/trace_k7/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
-d = sorted((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if "k_mlp_step" in r["Kernel_Name"])
-side = [(r["Kernel_Name"][:40], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3) for r in rows if any(k in r["Kernel_Name"] for k in ("k_mt_fill", "k_fy_accept"))]
-big = [x for n, x in side if x > 50]
-print("K7 n=%d mean=%.1f median=%.1f p90=%.1f max=%.1f | shuffle fill/accept (>50us) mean=%.1f | ms_per_step=%.3f" % (
-    len(d), st.mean(d), st.median(d), d[int(0.9 * len(d))], d[-1], st.mean(big) if big else 0, json.load(open("/tmp/k7_bench.json"))["ms_per_step"]))
+def dur(key):
+    return sorted((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if key in r["Kernel_Name"])
+d = dur("k_mlp_step")
+msg = "K7 n=%d mean=%.1f median=%.1f p90=%.1f max=%.1f" % (len(d), st.mean(d), st.median(d), d[int(0.9 * len(d))], d[-1])
+for k in ("k_mt_fill", "k_fy_accept", "k_fy_link", "k_fy_resolve", "k_mlp_reduce", "k_adv_stats"):
+    x = [v for v in dur(k) if v > 3]
+    if x: msg += " | %s mean=%.1f p90=%.1f" % (k, st.mean(x), x[int(0.9 * len(x))])
+print(msg + " | ms_per_step=%.3f" % json.load(open("/tmp/k7_bench.json"))["ms_per_step"])
 PY
 rm -rf gpurun_out/trace_k7

@@ -1,13 +1,16 @@
-"""Diagnostic: build mlp.hip with -DAURPPO_MLP_STAMPS into a SEPARATE library, run one fused step at the
-BASELINE minibatch size and print wave 0's cycle share per phase (median over workgroups)."""
+"""Diagnostic: build the MLP kernels with -DAURPPO_MLP_STAMPS into a SEPARATE library, run one fused step at the
+BASELINE minibatch size and print cycle shares per phase (median over workgroups).
+AURPPO_MLP_VARIANT=1: wave 0 of k_mlp_step.  Default (2): wave 0 of each tile set of k_mlp_step2, work and
+barrier-wait cycles per phase."""
 import ctypes as C, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 so = "/tmp/libaurppo_stamps.so"
 csrc = os.path.join(ROOT, "aur_ppo_amd", "csrc")
+import __graft_entry__ as g
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-                "-DAURPPO_MLP_STAMPS"] + [os.path.join(csrc, f) for f in ("gae.hip", "shuffle.hip", "gather.hip", "loss.hip", "clip.hip", "mlp.hip", "api.hip")] + ["-o", so], check=True)
+                "-DAURPPO_MLP_STAMPS"] + [os.path.join(csrc, f) for f in g.HIP_SOURCES] + ["-o", so], check=True)
 from aur_ppo_amd import _lib, hip_ops as H
 _lib.LIB_PATH = so
 _lib._lib = None
@@ -18,17 +21,30 @@ M = 131072
 idx = torch.randperm(obs.shape[0], device="cuda")[:M].int()
 lib = _lib.load()
 n = lay["n_params"]
-ws_bytes = lib.aurppo_mlp_workspace_bytes(n)
 for _ in range(3):
     Hh.mlp_ppo_step(obs, act, rec, idx, bucket.flat_param, lay, bucket.flat_grad, 0.2, 0.0, 0.5)
 torch.cuda.synchronize()
 ws = H._ws_cache[("mlp", torch.cuda.current_device())]
 off = ((8 * (2 * 256 + 8 * 256) + 4 * 256 * n + 63) // 64) * 64
-st = ws[off:off + 8 * 16 * 256].view(torch.int64).view(256, 16).cpu().numpy().astype(np.float64)
-names = ["land X/act->LDS+bar", "issue prefetch", "L1 mma+tanh+bar", "L2 mma+tanh+bar", "head mma+bar", "loss lanes+bar",
-         "dH2,dZ2,dW3+bar", "dW2,dH1,dZ1+bar", "dZ1->LDS+bar", "dW1+bar", "(pre-slab)", "slab+reduce tail"]
-med = np.median(st, axis=0)
-tot = med[:12].sum()
-for k, nm in enumerate(names):
-    print(f"{nm:24s} {med[k]:12.0f} cycles  {100 * med[k] / tot:5.1f} %")
-print("total cycles (wave 0, median WG):", tot, " tiles per WG:", M // 32 // 256)
+variant = os.environ.get("AURPPO_MLP_VARIANT", "2")
+if variant == "1":
+    st = ws[off:off + 8 * 16 * 256].view(torch.int64).view(256, 16).cpu().numpy().astype(np.float64)
+    names = ["land X/act->LDS+bar", "issue prefetch", "L1 mma+tanh+bar", "L2 mma+tanh+bar", "head mma+bar", "loss lanes+bar",
+             "dH2,dZ2,dW3+bar", "dW2,dH1,dZ1+bar", "dZ1->LDS+bar", "dW1+bar", "(pre-slab)", "slab+reduce tail"]
+    st = st[st[:, 2] > 0]
+    med = np.median(st, axis=0)
+    tot = med[:12].sum()
+    for k, nm in enumerate(names):
+        print(f"{nm:24s} {med[k]:12.0f} cycles  {100 * med[k] / tot:5.1f} %")
+    print("total cycles (wave 0, median WG):", tot, " tiles per WG:", M // 32 // 256)
+else:
+    st = ws[off:off + 8 * 32 * 256].view(torch.int64).view(256, 2, 16).cpu().numpy().astype(np.float64)
+    st = st[st[:, 0, 1] > 0]
+    names = ["S  land tile, prefetch", "F1 layer 1 + tanh", "F2 layer 2 + tanh", "F3 head", "L  loss lanes", "B1 dH2,dW3,dZ2",
+             "B2 dW2,dH1,dZ1", "B3 dW1"]
+    med = np.median(st, axis=0)     # (2, 16)
+    for s_ in range(2):
+        tot = med[s_].sum()
+        print(f"-- set {s_}: total {tot:.0f} cycles over the tile loop ({st.shape[0]} workgroups with work)")
+        for k, nm in enumerate(names):
+            print(f"   {nm:24s} work {med[s_, k]:10.0f} ({100 * med[s_, k] / tot:5.1f} %)   barrier wait {med[s_, 8 + k]:10.0f} ({100 * med[s_, 8 + k] / tot:5.1f} %)")
