@@ -25,6 +25,7 @@
 //      almost always empty, so each element resolves with a handful of L2-resident loads.
 // The generator state (key[624], pos) stays on the device between calls, like numpy's global stream.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -88,13 +89,25 @@ __device__ __forceinline__ uint32_t mt_untemper(uint32_t y) {
 }
 
 constexpr int kFillThreads = 256;
+// The first kRingMirror words of the ring are repeated after its end, so a reader may take up to kRingMirror
+// consecutive words from any slot with one straight (vector) access.
+constexpr int kRingMirror = 64;
 
-// Append freshly twisted blocks to the ring so that (words written - words consumed) reaches `target`
-// words (at most nblk_max blocks).  Continues from d_last; all bookkeeping is on the device.
+// Append freshly twisted words to the ring so that (words written - words consumed) reaches `target` words (whole
+// 624-word blocks, at most nblk_max).  Continues from d_last; all bookkeeping is on the device.
+//
+// The recurrence is x[m] = x[m-227] ^ mix(x[m-624], x[m-623]).  Taken 227 words at a time ("phase"), with thread
+// t owning offset t of EVERY phase, the x[m-227] term is the thread's own previous output -- a register.  The two
+// other inputs were written at least two phases earlier, so they are read from a small circular window in LDS one
+// phase ahead of their use.  What is left on the critical path of a phase is one XOR, one LDS write and one
+// barrier; tempering and the (coalesced) ring store hang off the side.  The block formulation this replaces needed
+// three barrier-separated passes with an LDS round trip each per 624 words.
+constexpr int kFillWin = 2048;   // LDS window over the untempered stream (power of two, >= 624 + 2 * 227)
+
 __global__ __launch_bounds__(kFillThreads) void k_mt_fill(uint32_t* __restrict__ last, uint32_t* __restrict__ ring,
                                                           long long ring_cap, long long* __restrict__ posv,
                                                           long long target, int nblk_max, int cur_slot) {
-    __shared__ uint32_t buf[2][kMtN];
+    __shared__ uint32_t win[kFillWin];
     const int tid = threadIdx.x;
     const long long S = posv[0];
     // Cursor as of the end of a SPECIFIC earlier shuffle (slot 4/5 by parity; slot 1 = live value for the
@@ -105,49 +118,56 @@ __global__ __launch_bounds__(kFillThreads) void k_mt_fill(uint32_t* __restrict__
     int nblk = want > 0 ? (int)((want + kMtN - 1) / kMtN) : 0;
     if (nblk > nblk_max) nblk = nblk_max;
     if (nblk == 0) return;
-    for (int k = tid; k < kMtN; k += kFillThreads) buf[0][k] = last[k];
+    // local numbering: x[0 .. 624) is the last block of the previous call, new words are x[624 ..  624 + total)
+    const int total = nblk * kMtN;
+    const int m_end = kMtN + total;
+    for (int k = tid; k < kMtN; k += kFillThreads) win[k] = last[k];
     __syncthreads();
-    long long out = S;
-    long long wpos = S % ring_cap;
-    int cb = 0;
-    for (int b = 0; b < nblk; ++b) {
-        const uint32_t* o = buf[cb];
-        uint32_t* w = buf[cb ^ 1];
-        if (tid < kMtD) w[tid] = o[tid + kMtM] ^ mt_mix(o[tid], o[tid + 1]);          // k in [0, 227)
-        __syncthreads();
-        if (tid < kMtD) {                                                                // k in [227, 454)
-            const int k = tid + kMtD;
-            w[k] = w[k - kMtD] ^ mt_mix(o[k], o[k + 1]);
+    const bool lane_on = tid < kMtD;
+    int m = kMtN + tid;                                         // my word of phase 0
+    uint32_t prev = lane_on ? win[kMtM + tid] : 0u;             // x[m - 227]
+    uint32_t a = win[tid & (kFillWin - 1)], b = win[(tid + 1) & (kFillWin - 1)];   // x[m - 624], x[m - 623]
+    long long at = S % ring_cap + tid;                          // ring slot of x[m]
+    if (at >= ring_cap) at -= ring_cap;
+    const int nphase = (total + kMtD - 1) / kMtD;
+    for (int p = 0; p < nphase; ++p) {
+        const bool on = lane_on && m < m_end;
+        // next phase's inputs first, so that their LDS latency runs under this phase's arithmetic: x[m + 227 - 624]
+        // and its successor were written in phase p-1 at the latest (the barrier below orders phase p-1 before us)
+        const uint32_t an = win[(m - kMtM) & (kFillWin - 1)];
+        const uint32_t bn = win[(m - kMtM + 1) & (kFillWin - 1)];
+        const uint32_t nw = prev ^ mt_mix(a, b);
+        if (on) win[m & (kFillWin - 1)] = nw;
+        prev = nw;
+        if (on) {
+            const uint32_t t = mt_temper(nw);
+            ring[at] = t;
+            if (at < kRingMirror) ring[ring_cap + at] = t;
         }
+        m += kMtD;
+        at += kMtD;
+        if (at >= ring_cap) at -= ring_cap;
+        a = an;
+        b = bn;
         __syncthreads();
-        if (tid < kMtN - 2 * kMtD) {                                                     // k in [454, 624)
-            const int k = tid + 2 * kMtD;
-            w[k] = w[k - kMtD] ^ mt_mix(o[k], k == kMtN - 1 ? w[0] : o[k + 1]);
-        }
-        __syncthreads();
-        for (int k = tid; k < kMtN; k += kFillThreads) {
-            long long at = wpos + k;
-            if (at >= ring_cap) at -= ring_cap;
-            ring[at] = mt_temper(w[k]);
-        }
-        out += kMtN;
-        wpos += kMtN;
-        if (wpos >= ring_cap) wpos -= ring_cap;
-        cb ^= 1;
     }
-    for (int k = tid; k < kMtN; k += kFillThreads) last[k] = buf[cb][k];
-    if (tid == 0) posv[0] = out;
+    for (int k = tid; k < kMtN; k += kFillThreads) last[k] = win[(m_end - kMtN + k) & (kFillWin - 1)];
+    if (tid == 0) posv[0] = S + total;
 }
 
 // (Re)start the stream at a generator state: ring[0 .. 624-pos) = temper(key[pos..]), last block = key
 __global__ __launch_bounds__(kFillThreads) void k_mt_origin(const uint32_t* __restrict__ state,
                                                             uint32_t* __restrict__ last, uint32_t* __restrict__ ring,
-                                                            long long* __restrict__ posv) {
+                                                            long long ring_cap, long long* __restrict__ posv) {
     const int tid = threadIdx.x;
     const int pos = (int)state[kMtN];
     for (int k = tid; k < kMtN; k += kFillThreads) {
         last[k] = state[k];
-        if (k >= pos) ring[k - pos] = mt_temper(state[k]);
+        if (k >= pos) {
+            const uint32_t t = mt_temper(state[k]);
+            ring[k - pos] = t;
+            if (k - pos < kRingMirror) ring[ring_cap + (k - pos)] = t;
+        }
     }
     if (tid == 0) {
         posv[0] = kMtN - pos;
@@ -179,77 +199,114 @@ __global__ __launch_bounds__(kFillThreads) void k_state_at_cursor(const uint32_t
     if (tid == 0) out[kMtN] = (uint32_t)pos;
 }
 
-constexpr int kAccThreads = 1024;
-constexpr int kWpt = 8;                       // draws per thread per step
-constexpr int kAccStep = kAccThreads * kWpt;  // 8192 draws per step
+// Diagnostic build only (tools/accept_stamps.py, -DAURPPO_ACC_STAMPS): thread 0 accumulates cycles per section of
+// a step into posv[8..]; the product library is built without it.
+#ifdef AURPPO_ACC_STAMPS
+#define ASTAMP(k)                                                      \
+    do {                                                               \
+        if (tid == 0) {                                                \
+            const unsigned long long t__ = __builtin_readcyclecounter(); \
+            st_acc[k] += t__ - st_last;                                \
+            st_last = t__;                                             \
+        }                                                              \
+    } while (0)
+#else
+#define ASTAMP(k) do { } while (0)
+#endif
 
+// Wave-wide inclusive prefix sum with DPP moves only (no LDS): row_shr 1/2/4/8 inside each row of 16 lanes, then
+// row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_add(int v) {
+    return v + __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ int row_incl_scan(int v) {   // within rows of 16 lanes
+    v = dpp_add<0x111, 0xf>(v);
+    v = dpp_add<0x112, 0xf>(v);
+    v = dpp_add<0x114, 0xf>(v);
+    v = dpp_add<0x118, 0xf>(v);
+    return v;
+}
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    v = row_incl_scan(v);
+    v = dpp_add<0x142, 0xa>(v);
+    v = dpp_add<0x143, 0xc>(v);
+    return v;
+}
+
+// kWpt = draws per thread per step.
+//
+// One step: every thread owns kWpt consecutive draws.  Whether a draw is accepted depends on the index it is
+// tried against, i.e. on the number of accepts before it; a thread resolves its own draws exactly given its
+// starting index i0, and the starting indices are the fixed point of "i0 = i_cur - (#accepts of earlier threads)".
+// Round: publish the per-wave accept counts (+ "did any of my counts change in the last evaluation"), ONE
+// barrier, every wave rebuilds its base from the 16 wave sums; when nobody changed, (excl, cnt) is the solution.
+// Common case per evaluation (count_fast): all of a thread's draws sit in one mask octave and none falls in the
+// window (i0 - kWpt, i0] the index moves through, so "#draws <= i0 - kWpt" is the count -- ~5 VALU ops per draw.
+// Anything else (octave edge, tail of the shuffle, a draw inside the window) sends the whole wave through the
+// literal per-draw loop behind a wave-uniform branch, so the fast path never pays for it.
+template <int kAccThreads, int kWpt>
 __global__ __launch_bounds__(kAccThreads) void k_fy_accept(const uint32_t* __restrict__ ring, long long ring_cap,
                                                            int32_t* __restrict__ j, int n,
                                                            long long* __restrict__ posv, int done_slot) {
-    __shared__ int s_wsum[kAccThreads / kWave];
-    __shared__ int s_changed[2];
+    constexpr int kAccStep = kAccThreads * kWpt;
+    constexpr int kWaves = kAccThreads / kWave;   // <= 16: one row of lanes reads all wave sums
+    static_assert(kWaves >= 1 && kWaves <= 16, "wave sums are combined inside one DPP row");
+    __shared__ int s_wsum[2][kWaves];
+    __shared__ int s_chg[2][kWaves];
     __shared__ int s_end;
-    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
-    if (tid == 0) s_changed[0] = s_changed[1] = 0;
-    __syncthreads();
+    const int tid = threadIdx.x, lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     long long cursor = posv[1];               // stream offset of the next unread draw
     const long long avail = posv[0];          // draws written so far (the fill for this shuffle has completed)
+    long long rpos = cursor % ring_cap;       // cursor's slot in the ring, kept incrementally
     int i_cur = n - 1;                        // next index to draw a target for
     float rate = 0.72f;                        // acceptance rate guess, refreshed every step
+    int par = 0;                              // exchange-buffer parity (runs on across steps)
     // this step's draws are fetched one step ahead (every step but the last consumes exactly kAccStep)
     uint32_t ynext[kWpt];
-    auto fetch = [&](long long cur) {
-        const long long b0 = cur + (long long)tid * kWpt;
-        long long r0 = b0 % ring_cap;
+    // Branch-free: draws past `avail` are fetched from some valid ring slot and never looked at (nhave below),
+    // so the loads are straight-line code and the wait at the top of the next step is for exactly these loads.
+    // A thread's kWpt consecutive words come as 16-byte vector loads (4-byte aligned: the cursor is arbitrary);
+    // dword loads at this stride cost one cache-line access per lane per word -- the vector memory pipe, not the
+    // arithmetic, was what a step waited for.  The ring's mirrored head makes the run contiguous at the wrap.
+    static_assert(kWpt % 4 == 0 && kWpt <= kRingMirror, "draws are fetched four at a time from a mirrored ring");
+    typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    auto fetch = [&](long long rp) {
+        long long r0 = rp + (long long)tid * kWpt;
+        if (r0 >= ring_cap) r0 -= ring_cap;
+        if (r0 >= ring_cap) r0 = 0;
+        const u32x4u* src = reinterpret_cast<const u32x4u*>(ring + r0);
 #pragma unroll
-        for (int u = 0; u < kWpt; ++u) {
-            long long at = r0 + u;
-            if (at >= ring_cap) at -= ring_cap;
-            ynext[u] = (b0 + u) < avail ? ring[at] : 0u;
+        for (int q = 0; q < kWpt / 4; ++q) {
+            const u32x4u v = src[q];
+            ynext[4 * q + 0] = v.x; ynext[4 * q + 1] = v.y; ynext[4 * q + 2] = v.z; ynext[4 * q + 3] = v.w;
         }
     };
-    fetch(cursor);
+    fetch(rpos);
+#ifdef AURPPO_ACC_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_readcyclecounter(), n_steps = 0, n_iters = 0;
+#endif
     while (i_cur >= 1 && cursor < avail) {
         const long long base = cursor + (long long)tid * kWpt;
         uint32_t y[kWpt];
-        int nhave = 0;                             // my draws that exist (a prefix of the 8)
+        int nhave = 0;                             // my draws that exist (a prefix of the kWpt)
 #pragma unroll
         for (int u = 0; u < kWpt; ++u) {
             y[u] = ynext[u];
             nhave += (base + u) < avail ? 1 : 0;
         }
-        fetch(cursor + kAccStep);
-        // My draws resolved exactly from a starting index i0; returns #accepted (and #consumed).
-        // Fast path: with i0 > 8 in one mask octave, a draw v is accepted iff v <= i, and i only moves
-        // inside (i0-8, i0]; if no draw lands in that window, "v <= i0" decides all eight at once.
-        auto run = [&](int i0, bool emit, int& consumed) -> int {
-            consumed = 0;
-            if (i0 < 1) return 0;
-            if (nhave == kWpt && i0 > kWpt && __clz(i0) == __clz(i0 - kWpt)) {
-                const uint32_t mask = 0xffffffffu >> __clz(i0);
-                const uint32_t lo = (uint32_t)(i0 - kWpt);
-                int acc = 0;
-                bool fragile = false;
-#pragma unroll
-                for (int u = 0; u < kWpt; ++u) {
-                    const uint32_t v = y[u] & mask;
-                    fragile |= (v > lo) && (v <= (uint32_t)i0);
-                    acc += v <= lo ? 1 : 0;
-                }
-                if (!fragile) {
-                    consumed = kWpt;
-                    if (emit) {
-                        int i = i0;
-#pragma unroll
-                        for (int u = 0; u < kWpt; ++u) {
-                            const uint32_t v = y[u] & mask;
-                            if (v <= lo) j[i--] = (int32_t)v;
-                        }
-                    }
-                    return acc;
-                }
-            }
+        ASTAMP(0);   // draws of this step in registers (waits for the fetch issued one step ago)
+        {
+            long long rn = rpos + kAccStep;
+            if (rn >= ring_cap) rn -= ring_cap;
+            fetch(rn);
+        }
+        ASTAMP(1);   // next fetch issued
+        // the literal rule for my draws from starting index i0: #accepted; optionally emits targets / #consumed
+        auto walk = [&](int i0, bool emit, int& consumed) -> int {
             int i = i0, acc = 0;
+            consumed = 0;
 #pragma unroll
             for (int u = 0; u < kWpt; ++u) {
                 if (u < nhave && i >= 1) {
@@ -264,52 +321,125 @@ __global__ __launch_bounds__(kAccThreads) void k_fy_accept(const uint32_t* __res
             }
             return acc;
         };
-        int excl = (int)(rate * (float)(tid * kWpt));   // first guess of #accepts before my draws
-        int consumed = 0;
-        int cnt = run(i_cur - excl, false, consumed);
+        // Shortcut evaluation at starting index i0.  Returns #draws <= i0 - kWpt and the slack of that count: it
+        // stays the same (and the shortcut stays valid) while i0 moves up by at most `up - kWpt` or down by at most
+        // `dn` -- the distances from i0 - kWpt to the nearest draw above / at-or-below it.
+        uint32_t dn = 0, up = 0;
+        bool sure = false;
+        int ref_i0 = 0;          // where (cnt, dn, up) were evaluated
+        bool wave_fast = false;  // every lane of this wave is on the shortcut
+        auto eval = [&](int i0) -> int {
+            const bool shape = nhave == kWpt && i0 > kWpt && __clz(i0) == __clz(i0 - kWpt);
+            const uint32_t mask = 0xffffffffu >> __clz(i0 | 1);
+            const uint32_t lo = (uint32_t)(i0 - kWpt);
+            int c = 0;
+            uint32_t d = 0xffffffffu, p = 0xffffffffu;
+#pragma unroll
+            for (int u = 0; u < kWpt; ++u) {
+                const uint32_t v = y[u] & mask;
+                const bool le = v <= lo;
+                c += le ? 1 : 0;
+                d = le ? min(d, lo - v) : d;
+                p = le ? p : min(p, v - lo - 1u);
+            }
+            dn = d;
+            up = p;
+            sure = shape && p >= (uint32_t)kWpt;      // no draw inside the window (i0 - kWpt, i0] the index moves through
+            ref_i0 = i0;
+            wave_fast = __builtin_amdgcn_ballot_w64(!sure) == 0ull;
+            if (!wave_fast) {   // wave-uniform and rare: the literal rule for everybody
+                int consumed;
+                c = walk(i0, false, consumed);
+            }
+            return c;
+        };
+        // is (cnt, shortcut) evaluated at ref_i0 still right at i0?
+        auto still_ok = [&](int i0) -> bool {
+            const int delta = i0 - ref_i0;
+            const bool shape = i0 > kWpt && __clz(i0) == __clz(i0 - kWpt) && __clz(i0) == __clz(ref_i0);
+            const bool room = delta >= 0 ? up >= (uint32_t)(kWpt + delta) : dn >= (uint32_t)(-delta);
+            return delta == 0 || (sure && shape && room);
+        };
+        int cur_i0 = i_cur - (int)(rate * (float)(tid * kWpt));   // first guess of my starting index
+        int cnt = eval(cur_i0);
+        int incl = wave_incl_scan(cnt);
+        bool wchg = true;                                // forces the first exchange
         int total = 0;
-        for (int it = 0;; ++it) {
-            // block-wide exclusive prefix sum of cnt
-            int incl = cnt;
-#pragma unroll
-            for (int off = 1; off < kWave; off <<= 1) {
-                const int t = __shfl_up(incl, off, kWave);
-                if (lane >= off) incl += t;
+        ASTAMP(2);   // first guess
+        for (;;) {
+#ifdef AURPPO_ACC_STAMPS
+            ++n_iters;
+#endif
+            if (lane == kWave - 1) {
+                s_wsum[par][wave] = incl;
+                s_chg[par][wave] = wchg ? 1 : 0;
             }
-            if (lane == kWave - 1) s_wsum[wave] = incl;
-            if (tid == 0) s_changed[(it + 1) & 1] = 0;
+            ASTAMP(6);   // (inside the loop) publish
             __syncthreads();
-            int wbase = 0;
-            total = 0;
-#pragma unroll
-            for (int w = 0; w < kAccThreads / kWave; ++w) {
-                const int c = s_wsum[w];
-                total += c;
-                wbase += (w < wave) ? c : 0;
+            ASTAMP(7);   // (inside the loop) barrier
+            const int ws = lane < kWaves ? s_wsum[par][lane] : 0;
+            const int wc = lane < kWaves ? s_chg[par][lane] : 0;
+            par ^= 1;
+            const int pre = row_incl_scan(ws);                          // lanes 0..15: prefix over the wave sums
+            total = __builtin_amdgcn_readlane(pre, kWaves - 1);
+            const int wbase = wave > 0 ? __builtin_amdgcn_readlane(pre, wave > 0 ? wave - 1 : 0) : 0;
+            const bool any = __builtin_amdgcn_ballot_w64(wc != 0) != 0ull;
+            if (!any) break;     // no wave's counts moved in the last evaluation: (cur_i0, cnt) is the fixed point
+            cur_i0 = i_cur - (wbase + incl - cnt);
+            // A lane recounts only if its index left the slack of its last evaluation; a wave whose lanes all
+            // stay inside keeps its counts, its scan and its published sum (typical: one or two waves per step redo).
+            if (__builtin_amdgcn_ballot_w64(!still_ok(cur_i0)) == 0ull) {
+                wchg = false;
+            } else {
+                const int cnt2 = eval(cur_i0);
+                wchg = __builtin_amdgcn_ballot_w64(cnt2 != cnt) != 0ull;
+                cnt = cnt2;
+                incl = wave_incl_scan(cnt);
             }
-            const int new_excl = wbase + incl - cnt;
-            const int cnt2 = run(i_cur - new_excl, false, consumed);
-            // (new_excl, cnt2) is the solution as soon as no thread's count moved: prefix(cnt2) == new_excl
-            if (cnt2 != cnt) s_changed[it & 1] = 1;
-            excl = new_excl;
-            cnt = cnt2;
-            __syncthreads();
-            if (!s_changed[it & 1]) break;
         }
-        (void)run(i_cur - excl, true, consumed);   // decisions are final: emit the targets
-        // words consumed this step: everything up to and including the draw that filled i = 1
-        const int my_end_i = i_cur - excl - cnt;    // index after my draws
-        if (tid == 0) s_end = -1;
-        __syncthreads();
-        if (cnt > 0 && my_end_i == 0) s_end = tid * kWpt + consumed;   // unique thread: filled i = 1
-        __syncthreads();
+        ASTAMP(3);   // fixed point reached
+        // decisions are final: emit the targets
+        int consumed = kWpt;
+        if (!wave_fast) {
+            (void)walk(cur_i0, true, consumed);
+        } else {
+            const uint32_t mask = 0xffffffffu >> __clz(cur_i0 | 1);
+            const uint32_t lo = (uint32_t)(cur_i0 - kWpt);
+            int i = cur_i0;
+#pragma unroll
+            for (int u = 0; u < kWpt; ++u) {
+                const uint32_t v = y[u] & mask;
+                if (v <= lo) j[i--] = (int32_t)v;
+            }
+        }
+        ASTAMP(4);   // targets emitted
         long long step_words = avail - cursor < kAccStep ? avail - cursor : kAccStep;
-        if (total >= i_cur) step_words = s_end;
+        if (total >= i_cur) {
+            // last step: words consumed = everything up to and including the draw that filled i = 1
+            const int my_end_i = cur_i0 - cnt;          // index after my draws
+            if (tid == 0) s_end = -1;
+            __syncthreads();
+            if (cnt > 0 && my_end_i == 0) s_end = tid * kWpt + consumed;   // unique thread
+            __syncthreads();
+            step_words = s_end;
+        }
         rate = step_words > 0 ? (float)total / (float)step_words : rate;
         i_cur -= total;
         cursor += step_words;
-        __syncthreads();
+        rpos += step_words;
+        if (rpos >= ring_cap) rpos -= ring_cap;
+        ASTAMP(5);   // step bookkeeping
+#ifdef AURPPO_ACC_STAMPS
+        ++n_steps;
+#endif
     }
+#ifdef AURPPO_ACC_STAMPS
+    if (tid == 0) {
+        for (int k = 0; k < 8; ++k) posv[8 + k] = (long long)st_acc[k];
+        posv[16] = (long long)n_steps;
+        posv[17] = (long long)n_iters;
+    }
+#endif
     if (tid == 0) {
         posv[1] = cursor;
         posv[done_slot] = cursor;      // this shuffle's final cursor, for the fill two shuffles later
@@ -413,8 +543,25 @@ int permute_once(aurppo_rng* rng, const int32_t* in, int32_t* out, int n, hipStr
         rng->primed_need = need;
     }
     AURPPO_HIP_TRY(hipStreamWaitEvent(s, rng->ev_fill[slot], 0));
-    hipLaunchKernelGGL(k_fy_accept, dim3(1), dim3(kAccThreads), 0, s, rng->d_ring, (long long)rng->ring_cap, rng->d_j, n,
-                       rng->d_pos, 4 + slot);
+    static int shape = -1;
+    if (shape < 0) {
+        const char* e = getenv("AURPPO_ACC_SHAPE");   // experiments only: threads * 100 + draws per thread
+        shape = e && *e ? atoi(e) : 102408;
+    }
+#define AURPPO_ACC_LAUNCH(T, W)                                                                                       \
+    hipLaunchKernelGGL((k_fy_accept<T, W>), dim3(1), dim3(T), 0, s, rng->d_ring, (long long)rng->ring_cap, rng->d_j, n, \
+                       rng->d_pos, 4 + slot)
+    switch (shape) {
+        case 25632: AURPPO_ACC_LAUNCH(256, 32); break;
+        case 25616: AURPPO_ACC_LAUNCH(256, 16); break;
+        case 51216: AURPPO_ACC_LAUNCH(512, 16); break;
+        case 51232: AURPPO_ACC_LAUNCH(512, 32); break;
+        case 102416: AURPPO_ACC_LAUNCH(1024, 16); break;
+        case 102432: AURPPO_ACC_LAUNCH(1024, 32); break;
+        case 51208: AURPPO_ACC_LAUNCH(512, 8); break;
+        default: AURPPO_ACC_LAUNCH(1024, 8);
+    }
+#undef AURPPO_ACC_LAUNCH
     AURPPO_LAUNCH_CHECK("k_fy_accept");
     // Look-ahead: the NEXT shuffle's draws (assumed the same size) are twisted on the fill stream while
     // this shuffle's accept / link / resolve run here.  It is ordered after the PREVIOUS accept (ev_acc of
@@ -442,7 +589,8 @@ int permute_once(aurppo_rng* rng, const int32_t* in, int32_t* out, int n, hipStr
 // Drain the look-ahead and restart the stream at d_state (after seed / set_state wrote it on `s`).
 static int restart_stream(aurppo_rng* rng, hipStream_t s) {
     AURPPO_HIP_TRY(hipStreamSynchronize(rng->fill_stream));
-    hipLaunchKernelGGL(k_mt_origin, dim3(1), dim3(kFillThreads), 0, s, rng->d_state, rng->d_last, rng->d_ring, rng->d_pos);
+    hipLaunchKernelGGL(k_mt_origin, dim3(1), dim3(kFillThreads), 0, s, rng->d_state, rng->d_last, rng->d_ring,
+                       (long long)rng->ring_cap, rng->d_pos);
     AURPPO_LAUNCH_CHECK("k_mt_origin");
     rng->seq = 0;
     rng->primed_need = 0.0;
@@ -463,8 +611,8 @@ extern "C" int aurppo_mt19937_create(aurppo_rng** out, uint32_t seed, int max_n,
     const size_t nb = sizeof(int32_t) * (size_t)max_n;
     hipError_t e = hipMalloc(&r->d_state, sizeof(uint32_t) * (kMtN + 1));
     if (e == hipSuccess) e = hipMalloc(&r->d_last, sizeof(uint32_t) * kMtN);
-    if (e == hipSuccess) e = hipMalloc(&r->d_ring, sizeof(uint32_t) * r->ring_cap);
-    if (e == hipSuccess) e = hipMalloc(&r->d_pos, sizeof(long long) * 8);
+    if (e == hipSuccess) e = hipMalloc(&r->d_ring, sizeof(uint32_t) * (r->ring_cap + kRingMirror));
+    if (e == hipSuccess) e = hipMalloc(&r->d_pos, sizeof(long long) * 32);
     if (e == hipSuccess) e = hipMalloc(&r->d_j, nb);
     if (e == hipSuccess) e = hipMalloc(&r->d_head, nb);
     if (e == hipSuccess) e = hipMalloc(&r->d_next, nb);
@@ -520,6 +668,12 @@ extern "C" int aurppo_mt19937_seed(aurppo_rng* rng, uint32_t seed, void* stream)
     AURPPO_LAUNCH_CHECK("k_mt_seed");
     return restart_stream(rng, (hipStream_t)stream);
 }
+
+#ifdef AURPPO_ACC_STAMPS
+extern "C" int aurppo_debug_accept_stamps(aurppo_rng* rng, long long* out24) {
+    return hipMemcpy(out24, rng->d_pos + 8, sizeof(long long) * 24, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int aurppo_mt19937_get_state(aurppo_rng* rng, uint32_t* key_h, int32_t* pos_h, void* stream) {
     AURPPO_REQUIRE(rng && key_h && pos_h, AURPPO_EINVAL, "aurppo_mt19937_get_state: null pointer");

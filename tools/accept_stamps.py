@@ -1,0 +1,31 @@
+"""Diagnostic: build the library with -DAURPPO_ACC_STAMPS into /tmp, run shuffles of 524288 and print where
+thread 0 of k_fy_accept spends its cycles per step."""
+import ctypes as C, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import __graft_entry__ as g
+so = "/tmp/libaurppo_accstamps.so"
+csrc = os.path.join(ROOT, "aur_ppo_amd", "csrc")
+subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+                "-DAURPPO_ACC_STAMPS"] + [os.path.join(csrc, f) for f in g.HIP_SOURCES] + ["-o", so], check=True)
+from aur_ppo_amd import _lib, hip_ops as H
+_lib.LIB_PATH = so
+_lib._lib = None
+n = 524288
+rng = H.MT19937(1, n)
+out = torch.empty((4, n), dtype=torch.int32, device="cuda")
+for _ in range(3):
+    rng.shuffle_epochs(n, 4, out=out)
+torch.cuda.synchronize()
+lib = _lib.load()
+buf = (C.c_longlong * 24)()
+lib.aurppo_debug_accept_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+assert lib.aurppo_debug_accept_stamps(rng._h, buf) == 0
+v = list(buf)
+names = ["wait draws", "issue next fetch", "first guess run", "rounds: combine + recount", "emit run", "bookkeeping", "rounds: scan + publish", "rounds: barrier"]
+steps, iters = v[8], v[9]
+tot = sum(v[:8])
+print(f"steps {steps}, fixed-point iterations {iters} ({iters / max(steps, 1):.2f} per step), total {tot} cycles")
+for k, nm in enumerate(names):
+    print(f"  {nm:20s} {v[k]:10d} cycles  {100 * v[k] / tot:5.1f} %   {v[k] / max(steps, 1):8.0f} per step")
