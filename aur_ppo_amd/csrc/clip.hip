@@ -5,7 +5,7 @@
 // RCCL all-reduce uses), so the clip is two small launches instead of torch's per-tensor norm /
 // stack / norm / per-tensor scale chain: fp64 partial sums of squares, then every workgroup
 // re-derives the norm in fixed order and scales its slice.
-#include "common.h"
+#include "adam_math.h"
 
 namespace {
 
@@ -101,37 +101,10 @@ __global__ __launch_bounds__(kThreads) void k_clip_adam(float* __restrict__ p, f
                                                         double eps, float* __restrict__ out_norm) {
     __shared__ double sc[kNW];
     __shared__ float s_coef;
-    double q = 0.0;
-    for (int b = threadIdx.x; b < n_part; b += kThreads) q += part[b];
-    const double t = block_sum<kNW>(q, sc);
-    if (threadIdx.x == 0) {
-        const float norm = (float)sqrt(t);
-        float coef = max_norm / (norm + 1e-6f);
-        s_coef = coef < 1.0f ? coef : 1.0f;
-        if (coef != coef) s_coef = coef;
-        if (blockIdx.x == 0) *out_norm = norm;
-    }
-    __syncthreads();
-    const float coef = s_coef;
-    const double tt = (double)*step;
-    const double bc1 = 1.0 - pow(beta1, tt);
-    const double bc2 = 1.0 - pow(beta2, tt);
-    const float step_size = (float)((double)*lr_dev / bc1);
-    const float bc2_sqrt = (float)sqrt(bc2);
-    const float w1 = (float)(1.0 - beta1), b2 = (float)beta2, w2 = (float)(1.0 - beta2), e = (float)eps;
-    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
-        float gi = g[i];
-        if (i < clip_n) {
-            gi = gi * coef;
-            g[i] = gi;   // the clipped gradient stays visible, as clip_grad_norm_ leaves it
-        }
-        const float mi = m[i] + w1 * (gi - m[i]);
-        const float vi = v[i] * b2 + (w2 * gi) * gi;
-        m[i] = mi;
-        v[i] = vi;
-        const float denom = sqrtf(vi) / bc2_sqrt + e;
-        p[i] = p[i] - step_size * (mi / denom);
-    }
+    const AdamScalars a = adam_scalars<kNW>(part, n_part, max_norm, lr_dev, step, beta1, beta2, eps, out_norm,
+                                            blockIdx.x == 0, sc, &s_coef);
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads)
+        (void)adam_update(p, g, m, v, i, i < clip_n, a);
 }
 
 }  // namespace

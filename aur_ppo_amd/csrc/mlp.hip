@@ -36,6 +36,7 @@
 #define STAMP(k) do { } while (0)
 #endif
 
+#include "adam_math.h"
 #include "mlp_common.h"
 
 using namespace aurppo_mlp;
@@ -601,9 +602,12 @@ constexpr size_t act_lds_bytes() {
 // 64 parameters x 16 slab groups per 1024-thread workgroup: every wave-instruction reads one coalesced
 // 256-B slab row, 16 rows per parameter are in flight at once, groups are combined through LDS in order.
 constexpr int kRedGroups = 16;
+// sq_part != nullptr (chained minibatch step): also the clip's partial sums of squares, one per workgroup, the Adam
+// step count is advanced and the tile counter of the next K7 launch is cleared.
 __global__ __launch_bounds__(1024) void k_mlp_reduce(const float* __restrict__ slabs, const double* __restrict__ loss_part,
                                                      int n_slabs, int n_params, PpoHyper h, float* __restrict__ grads,
-                                                     float* __restrict__ out_scalars) {
+                                                     float* __restrict__ out_scalars, double* __restrict__ sq_part,
+                                                     float* __restrict__ step_dev, unsigned* __restrict__ tile_counter) {
     __shared__ float s_part[kRedGroups][64];
     const int pi = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int p = blockIdx.x * 64 + pi;
@@ -622,11 +626,23 @@ __global__ __launch_bounds__(1024) void k_mlp_reduce(const float* __restrict__ s
     }
     s_part[grp][pi] = acc;
     __syncthreads();
-    if (grp == 0 && p < n_params) {
+    if (grp == 0) {   // wave 0
         float t = 0.0f;
+        if (p < n_params) {
 #pragma unroll
-        for (int g = 0; g < kRedGroups; ++g) t += s_part[g][pi];
-        grads[p] = t;
+            for (int g = 0; g < kRedGroups; ++g) t += s_part[g][pi];
+            grads[p] = t;
+        }
+        if (sq_part) {
+            const double q = wave_sum((double)t * (double)t);
+            if (pi == 0) {
+                sq_part[blockIdx.x] = q;
+                if (blockIdx.x == 0) {
+                    *step_dev += 1.0f;   // the Adam kernel (next launch) reads the new step count
+                    *tile_counter = 0u;
+                }
+            }
+        }
     }
     __shared__ double r[6];
     if (blockIdx.x == 0 && threadIdx.x < 6 * kWave) {
@@ -653,6 +669,50 @@ __global__ __launch_bounds__(1024) void k_mlp_reduce(const float* __restrict__ s
     }
 }
 
+// Chained minibatch step, third launch: global-norm clip + Adam over the bucket (K6b's arithmetic); the W1
+// elements it has just updated are dropped into the operand-order copy the next K7 launch streams; and the
+// workgroups past `nb_upd` form the next minibatch's advantage partial sums -- so nothing is left to prepare
+// before that launch.
+__global__ __launch_bounds__(kThreads) void k_adam_chain(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                         float* __restrict__ v, int n, const double* __restrict__ part,
+                                                         int n_part, float max_norm, const float* __restrict__ lr_dev,
+                                                         const float* __restrict__ step, double beta1, double beta2,
+                                                         double eps, float* __restrict__ out_norm, int nb_upd, int w1_actor,
+                                                         int w1_critic, int D, float* __restrict__ w1op,
+                                                         const float4* __restrict__ rec, const int32_t* __restrict__ next_idx,
+                                                         int next_M, double (*__restrict__ stats)[2]) {
+    __shared__ double sc[2][kThreads / kWave];
+    __shared__ float s_coef;
+    if ((int)blockIdx.x < nb_upd) {
+        const AdamScalars a = adam_scalars<kThreads / kWave>(part, n_part, max_norm, lr_dev, step, beta1, beta2, eps, out_norm,
+                                                             blockIdx.x == 0, sc[0], &s_coef);
+        for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += nb_upd * kThreads) {
+            const float pn = adam_update(p, g, m, v, i, true, a);
+            const int ea = i - w1_actor, ec = i - w1_critic;
+            const int e = (ea >= 0 && ea < H * D) ? ea : ((ec >= 0 && ec < H * D) ? ec : -1);
+            if (e >= 0) {
+                const int net = (ea >= 0 && ea < H * D) ? 0 : 1;
+                const int row = e / D, k = e - row * D;
+                w1op[((net * 2 + (row >> 5)) * 32 + (k >> 1)) * kWave + (row & 31) + 32 * (k & 1)] = pn;
+            }
+        }
+    } else {
+        const int nsb = gridDim.x - nb_upd, b = blockIdx.x - nb_upd;
+        double s = 0.0, q = 0.0;
+        for (int i = b * kThreads + threadIdx.x; i < next_M; i += nsb * kThreads) {
+            const double x = (double)rec[next_idx[i]].y;
+            s += x;
+            q += x * x;
+        }
+        const double bs = block_sum<kThreads / kWave>(s, sc[0]);
+        const double bq = block_sum<kThreads / kWave>(q, sc[1]);
+        if (threadIdx.x == 0) {
+            stats[b][0] = bs;
+            stats[b][1] = bq;
+        }
+    }
+}
+
 constexpr size_t lds_bytes() {
     // every term before sRec is a multiple of 4 floats, so the float4 array is 16-B aligned
     return sizeof(float) * (size_t)(R * LD + 3 * 2 * R * LD + 2 * 2 * H * LD + 2 * AP * LD + 2 * R * LDO + 4 * H + 2 * AP + 2 * AP +
@@ -663,13 +723,34 @@ constexpr size_t lds_bytes() {
 
 extern "C" size_t aurppo_mlp_workspace_bytes(int n_params) {
     return sizeof(double) * 2 * kStatBlocks + sizeof(double) * 8 * kMaxGrid + sizeof(float) * (size_t)kMaxGrid * (size_t)n_params + 64 +
-           sizeof(unsigned long long) * 32 * kMaxGrid + sizeof(float) * 4 * 32 * 64 + 64;
+           sizeof(unsigned long long) * 32 * kMaxGrid + sizeof(float) * 4 * 32 * 64 + 64 +
+           sizeof(double) * (size_t)((n_params + 63) / 64) + 64;
 }
+
+namespace {
+struct ChainArgs {   // the optimizer half of aurppo_mlp_ppo_minibatch_f32
+    float* params_rw;
+    float* exp_avg;
+    float* exp_avg_sq;
+    double max_norm;
+    const float* lr_dev;
+    float* step_dev;
+    double beta1, beta2, eps;
+    float* out_norm;
+    const int32_t* next_idx;
+    int next_M;
+    int chained;
+};
+int stat_blocks_for(int M) {
+    int sb = (M + kThreads * 4 - 1) / (kThreads * 4);
+    return sb > kStatBlocks ? kStatBlocks : sb;
+}
+}  // namespace
 
 static int mlp_step_impl(const float* obs, const float* actions, const float* rec, const int32_t* idx, int M, int D,
                          int A, int continuous, int hidden, const float* params, const int* layout_h, int n_params, float* grads,
                          double clip, double ent_coef, double vf_coef, int norm_adv, int vloss_mode, float* out_scalars,
-                         void* workspace, void* stream, void* ev_begin, void* ev_end) {
+                         void* workspace, void* stream, void* ev_begin, void* ev_end, const ChainArgs* chain = nullptr) {
     AURPPO_REQUIRE(obs && actions && rec && idx && params && layout_h && grads && out_scalars && workspace, AURPPO_EINVAL,
                    "aurppo_mlp_ppo_step_f32: null pointer");
     AURPPO_REQUIRE(hidden == H, AURPPO_ESHAPE, "aurppo_mlp_ppo_step_f32: hidden_dim=%d (only %d is built)", hidden, H);
@@ -702,8 +783,7 @@ static int mlp_step_impl(const float* obs, const float* actions, const float* re
     a.stamps = reinterpret_cast<unsigned long long*>(w + ((sizeof(double) * (2 * kStatBlocks + 8 * kMaxGrid) +
                                                             sizeof(float) * (size_t)kMaxGrid * (size_t)n_params + 63) / 64) * 64);
     hipStream_t s = (hipStream_t)stream;
-    int sb = (M + kThreads * 4 - 1) / (kThreads * 4);
-    if (sb > kStatBlocks) sb = kStatBlocks;
+    const int sb = stat_blocks_for(M);
     a.n_stat_blocks = sb;
     const char* ve = getenv("AURPPO_MLP_VARIANT");   // read per call so that a test can run both variants in one process
     const int variant = (ve && *ve == '1') ? 1 : 2;
@@ -713,10 +793,13 @@ static int mlp_step_impl(const float* obs, const float* actions, const float* re
         const char* se = getenv("AURPPO_MLP_SKEW");   // experiments only
         a.skew = (se && *se >= '0' && *se <= '7') ? *se - '0' : 3;
     }
-    hipLaunchKernelGGL(k_adv_stats_idx, dim3(sb), dim3(kThreads), 0, s, a.rec, idx, M,
-                       reinterpret_cast<double (*)[2]>(stats), params, a.L.w1[0], a.L.w1[1], D, variant == 2 ? a.w1op : nullptr,
-                       a.tile_counter);
-    AURPPO_LAUNCH_CHECK("k_adv_stats_idx");
+    double* sq_part = reinterpret_cast<double*>(a.tile_counter + 16);
+    if (!(chain && chain->chained)) {   // otherwise the previous chained call has prepared all of this
+        hipLaunchKernelGGL(k_adv_stats_idx, dim3(sb), dim3(kThreads), 0, s, a.rec, idx, M,
+                           reinterpret_cast<double (*)[2]>(stats), params, a.L.w1[0], a.L.w1[1], D,
+                           (variant == 2 || chain) ? a.w1op : nullptr, a.tile_counter);
+        AURPPO_LAUNCH_CHECK("k_adv_stats_idx");
+    }
     const int n_tiles = (M + R - 1) / R;
     // One persistent workgroup per CU, minus one CU per XCD (AURPPO_MLP_SPARE_CUS, default 8; workgroups are dealt
     // round-robin over the 8 XCDs): the single-workgroup shuffle kernels of the side stream then have a CU of
@@ -757,9 +840,21 @@ static int mlp_step_impl(const float* obs, const float* actions, const float* re
         AURPPO_LAUNCH_CHECK("k_mlp_step");
     }
     if (ev_end) AURPPO_HIP_TRY(hipEventRecord((hipEvent_t)ev_end, s));
-    hipLaunchKernelGGL(k_mlp_reduce, dim3((n_params + 63) / 64), dim3(1024), 0, s, a.slabs, a.loss_part, grid, n_params,
-                       a.h, grads, out_scalars);
+    const int n_red = (n_params + 63) / 64;
+    hipLaunchKernelGGL(k_mlp_reduce, dim3(n_red), dim3(1024), 0, s, a.slabs, a.loss_part, grid, n_params, a.h, grads,
+                       out_scalars, chain ? sq_part : nullptr, chain ? chain->step_dev : nullptr, a.tile_counter);
     AURPPO_LAUNCH_CHECK("k_mlp_reduce");
+    if (chain) {
+        int nb_upd = (n_params + kThreads * 4 - 1) / (kThreads * 4);
+        if (nb_upd > 64) nb_upd = 64;
+        const int nsb = chain->next_idx ? stat_blocks_for(chain->next_M) : 0;
+        hipLaunchKernelGGL(k_adam_chain, dim3(nb_upd + nsb), dim3(kThreads), 0, s, chain->params_rw, grads, chain->exp_avg,
+                           chain->exp_avg_sq, n_params, sq_part, n_red, (float)chain->max_norm, chain->lr_dev,
+                           chain->step_dev, chain->beta1, chain->beta2, chain->eps, chain->out_norm, nb_upd, a.L.w1[0],
+                           a.L.w1[1], D, a.w1op, a.rec, chain->next_idx, chain->next_M,
+                           reinterpret_cast<double (*)[2]>(stats));
+        AURPPO_LAUNCH_CHECK("k_adam_chain");
+    }
     return AURPPO_OK;
 }
 
@@ -778,6 +873,24 @@ extern "C" int aurppo_mlp_ppo_step_ev_f32(const float* obs, const float* actions
                                           void* stream, void* ev_begin, void* ev_end) {
     return mlp_step_impl(obs, actions, rec, idx, M, D, A, continuous, hidden, params, layout_h, n_params, grads, clip, ent_coef,
                          vf_coef, norm_adv, vloss_mode, out_scalars, workspace, stream, ev_begin, ev_end);
+}
+
+extern "C" int aurppo_mlp_ppo_minibatch_f32(const float* obs, const float* actions, const float* rec, const int32_t* idx, int M,
+                                            int D, int A, int continuous, int hidden, float* params, const int* layout_h,
+                                            int n_params, float* grads, double clip, double ent_coef, double vf_coef,
+                                            int norm_adv, int vloss_mode, float* out_scalars, float* exp_avg,
+                                            float* exp_avg_sq, double max_norm, const float* lr_dev, float* step_dev,
+                                            double beta1, double beta2, double eps, float* out_norm, const int32_t* next_idx,
+                                            int next_M, int chained, void* workspace, void* stream) {
+    AURPPO_REQUIRE(exp_avg && exp_avg_sq && lr_dev && step_dev && out_norm, AURPPO_EINVAL,
+                   "aurppo_mlp_ppo_minibatch_f32: null optimizer pointer");
+    AURPPO_REQUIRE(!next_idx || next_M > 0, AURPPO_ESHAPE, "aurppo_mlp_ppo_minibatch_f32: next_M=%d", next_M);
+    ChainArgs c;
+    c.params_rw = params; c.exp_avg = exp_avg; c.exp_avg_sq = exp_avg_sq; c.max_norm = max_norm; c.lr_dev = lr_dev;
+    c.step_dev = step_dev; c.beta1 = beta1; c.beta2 = beta2; c.eps = eps; c.out_norm = out_norm;
+    c.next_idx = next_idx; c.next_M = next_idx ? next_M : 0; c.chained = chained ? 1 : 0;
+    return mlp_step_impl(obs, actions, rec, idx, M, D, A, continuous, hidden, params, layout_h, n_params, grads, clip, ent_coef,
+                         vf_coef, norm_adv, vloss_mode, out_scalars, workspace, stream, nullptr, nullptr, &c);
 }
 
 extern "C" int aurppo_mlp_act_f32(const float* obs, const float* noise, int N, int D, int A, int continuous, int hidden,

@@ -140,6 +140,8 @@ class ppo:
         self._mlp = None
         if params.get("fused_mlp", True) and self.device.type == "cuda" and hasattr(ops, "mlp_layout"):
             self._mlp = ops.mlp_layout(self.policy, self.bucket)
+        # the flat bucket holds the MLP policy and nothing else (up to alignment padding): K7 + clip + Adam can chain
+        self._bucket_is_policy = self._mlp is not None and self.bucket.numel == self._mlp["n_params"]
         self._graph = None         # captured update (hipGraph), see update()
         self._graph_state = 0      # 0: next update runs eagerly (warm-up), 1: capture, 2: replay
         self._perm_static = None
@@ -351,10 +353,30 @@ class ppo:
         vmode = ops.VLOSS_CLIPPED if self.clip_vloss else ops.VLOSS_OLDVALUES   # src/ppo.py:250-261 (F8)
         B, M = self.batch_size, self.minibatch_size
         step = 0
+        # single process, MLP policy, fused Adam over exactly the policy's bucket: K7 + clip + Adam chained, three
+        # launches per minibatch (each call also prepares the statistics of the slice that follows it)
+        chain = (packed and self._mlp is not None and self.world == 1 and self._fused_adam
+                 and self._bucket_is_policy and hasattr(ops, "mlp_ppo_minibatch"))
+        starts = list(range(0, B, M))
         for ep in range(self.num_update_epochs):
             idx_ep = perms[ep]
-            for start in range(0, B, M):
+            for si, start in enumerate(starts):
                 mb_inds = idx_ep[start:start + M]
+                if chain:
+                    if si + 1 < len(starts):
+                        nxt = idx_ep[starts[si + 1]:starts[si + 1] + M]
+                    elif ep + 1 < self.num_update_epochs:
+                        nxt = perms[ep + 1][0:M]
+                    else:
+                        nxt = None
+                    g = self.optimizer.param_groups[0]
+                    ops.mlp_ppo_minibatch(b_obs, b_actions, self._rec, mb_inds, self.bucket.flat_param, self._mlp,
+                                          self.bucket.flat_grad, self.clip_coeff, self.entropy_coeff, self.value_coeff,
+                                          self.norm_adv, vmode, self._scalars[step], self._adam_m, self._adam_v,
+                                          self._lr_tensor, self._adam_t, self.max_grad_norm, g["betas"], g["eps"],
+                                          self._norms[step:step + 1], next_idx=nxt, chained=step > 0)
+                    step += 1
+                    continue
                 if packed and self._mlp is not None:
                     # one fused launch: rows are read through the permutation, gradients land in the bucket
                     ops.mlp_ppo_step(b_obs, b_actions, self._rec, mb_inds, self.bucket.flat_param, self._mlp,

@@ -171,6 +171,23 @@ int aurppo_mlp_ppo_step_ev_f32(const float* obs, const float* actions, const flo
                                float* out_scalars, void* workspace, void* stream, void* ev_begin,
                                void* ev_end);
 
+/* ---- K7 + K6b chained: one whole minibatch of the update loop ---------------------------------------
+ * Replaces src/ppo.py:219-269 for one minibatch -- everything aurppo_mlp_ppo_step_f32 does, then
+ * nn.utils.clip_grad_norm_(parameters, max_norm) and optimizer.step() (Adam, as aurppo_clip_adam_f32) over
+ * the same flat bucket of n_params floats (params / grads / exp_avg / exp_avg_sq), in three launches instead
+ * of five.  Single-process only: there is no place for a gradient all-reduce between the halves.
+ * next_idx / next_M: the index slice of the minibatch that will be stepped next (NULL: none); its advantage
+ * statistics and the operand copy of the updated first layer are prepared by this call's last launch.
+ * chained != 0 promises that the previous call on this workspace was this function with next_idx equal to this
+ * call's idx (same M); then nothing is prepared again.  lr_dev / step_dev / out_norm as aurppo_clip_adam_f32. */
+int aurppo_mlp_ppo_minibatch_f32(const float* obs, const float* actions, const float* rec, const int32_t* idx, int M,
+                                 int D, int A, int continuous, int hidden, float* params, const int* layout_h,
+                                 int n_params, float* grads, double clip, double ent_coef, double vf_coef,
+                                 int norm_adv, int vloss_mode, float* out_scalars, float* exp_avg,
+                                 float* exp_avg_sq, double max_norm, const float* lr_dev, float* step_dev,
+                                 double beta1, double beta2, double eps, float* out_norm, const int32_t* next_idx,
+                                 int next_M, int chained, void* workspace, void* stream);
+
 /* ---- K8: rollout step for the MLP actor-critic -----------------------------------------------------
  * Replaces `action, logprob, _, value = policy.evaluate(next_obs)` under no_grad and the three buffer row
  * stores that follow it (src/ppo.py:104-108), and with noise == NULL the bootstrap `policy.value(next_obs)`

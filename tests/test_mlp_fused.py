@@ -158,3 +158,50 @@ def test_act_kernel_matches_torch_formulas(N, D, A, cont):
     H.mlp_act(obs, noise, bucket.flat_param, lay, buf_a[1], buf_lp[1], buf_v[1])
     assert torch.equal(buf_a[1], actions) and torch.equal(buf_lp[1], logp) and torch.equal(buf_v[1], value)
     assert float(buf_a[0].abs().sum() + buf_a[2].abs().sum() + buf_v[0].abs().sum() + buf_lp[2].abs().sum()) == 0.0
+
+
+# ---------------------------------------------------------------------------------- K7 + K6b chained
+@pytest.mark.parametrize("cont", [True, False])
+def test_chained_minibatches_match_step_then_clip_adam(cont, variant):
+    """aurppo_mlp_ppo_minibatch_f32 over a run of minibatches (each call preparing the next) == the same run as
+    aurppo_mlp_ppo_step_f32 + aurppo_clip_adam_f32 pairs: parameters, moments, loss scalars and norms."""
+    T, N, D, A, M = 16, 64, 64 if cont else 6, 6 if cont else 5, 300      # B = 1024: three full slices and a ragged tail
+    H, pol, bucket, obs, act, rec = _setup(T, N, D, A, seed=3, cont=cont)
+    lay = H.mlp_layout(pol, bucket)
+    n = lay["n_params"]
+    nb = bucket.flat_param.numel()      # the bucket may carry alignment padding past the policy
+    assert nb >= n
+    perm = torch.randperm(T * N, device="cuda").int()
+    slices = [perm[s:s + M] for s in range(0, T * N, M)]
+    assert slices[-1].numel() not in (0, M)
+    p0 = bucket.flat_param.clone()
+
+    def run(chained):
+        bucket.flat_param.copy_(p0)
+        m, v = torch.zeros(nb, device="cuda"), torch.zeros(nb, device="cuda")
+        lr, t = torch.full((1,), 3e-3, device="cuda"), torch.zeros(1, device="cuda")
+        sc = torch.zeros(len(slices) * 2, 9, device="cuda")
+        norms = torch.zeros(len(slices) * 2, device="cuda")
+        g = torch.zeros(nb, device="cuda")
+        k = 0
+        for rep in range(2):
+            for i, idx in enumerate(slices):
+                if chained:
+                    nxt = slices[i + 1] if i + 1 < len(slices) else (slices[0] if rep == 0 else None)
+                    H.mlp_ppo_minibatch(obs, act, rec, idx, bucket.flat_param, lay, g, 0.2, 0.01, 0.5, True, 1, sc[k], m, v, lr, t,
+                                        0.5, (0.9, 0.999), 1e-5, norms[k:k + 1], next_idx=nxt, chained=k > 0)
+                else:
+                    H.mlp_ppo_step(obs, act, rec, idx, bucket.flat_param, lay, g, 0.2, 0.01, 0.5, True, 1, sc[k])
+                    H.clip_adam_(bucket.flat_param, g, m, v, lr, t, 0.5, None, (0.9, 0.999), 1e-5, norms[k:k + 1])
+                k += 1
+        torch.cuda.synchronize()
+        return bucket.flat_param.clone(), m, v, sc, norms, float(t)
+
+    ref = run(False)
+    got = run(True)
+    assert got[5] == ref[5] == 2 * len(slices)
+    torch.testing.assert_close(got[4], ref[4], rtol=1e-6, atol=0)
+    torch.testing.assert_close(got[3], ref[3], rtol=2e-5, atol=2e-6)
+    for a_, b_ in zip(got[:3], ref[:3]):
+        torch.testing.assert_close(a_, b_, rtol=1e-4, atol=1e-6)
+    assert float((ref[0] - p0).abs().max()) > 1e-3      # the run did move the parameters
