@@ -789,10 +789,6 @@ static int mlp_step_impl(const float* obs, const float* actions, const float* re
     const int variant = (ve && *ve == '1') ? 1 : 2;
     a.w1op = reinterpret_cast<float*>(a.stamps + 32 * kMaxGrid);
     a.tile_counter = reinterpret_cast<unsigned*>(a.w1op + 4 * 32 * 64);
-    {
-        const char* se = getenv("AURPPO_MLP_SKEW");   // experiments only
-        a.skew = (se && *se >= '0' && *se <= '7') ? *se - '0' : 3;
-    }
     double* sq_part = reinterpret_cast<double*>(a.tile_counter + 16);
     if (!(chain && chain->chained)) {   // otherwise the previous chained call has prepared all of this
         hipLaunchKernelGGL(k_adv_stats_idx, dim3(sb), dim3(kThreads), 0, s, a.rec, idx, M,

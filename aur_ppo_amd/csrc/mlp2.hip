@@ -5,10 +5,10 @@
 // s_memtime stamps of k_mlp_step (tools/mlp_stamps.py, profiles/r01) put only ~50 % of a workgroup's time in
 // MFMA chains: with one wave per SIMD nothing overlaps the epilogues, the loss lanes or the barriers.  Here a
 // workgroup is 8 waves = two independent TILE SETS of 4 waves (2 nets x 2 column halves, as before), so
-// every SIMD hosts one wave of each set, and the two sets run the eight phases of a tile
-//     S (land tile, prefetch next)  F1  F2  F3 (head)  L (loss lanes)  B1  B2  B3
-// `skew` phases apart: while one set is in an MFMA chain the other is typically in VALU / LDS work.  All
-// barriers stay workgroup-wide (one per phase slot), so no software barrier is needed.
+// every SIMD hosts one wave of each set, and each set runs the eight phases of a tile
+//     S (land tile)  F1  F2  F3 (head)  L (loss lanes)  B1  B2  B3
+// at its own pace: the four waves of a set synchronise on a counter in LDS (set_bar below), never on the
+// workgroup barrier, so while one set is in an MFMA chain the other is free to be in VALU / LDS work.
 //
 // What had to move to make two sets fit one CU (160 KB LDS, 256 VGPRs per wave at 2 waves/SIMD):
 //   * W1 is only ever a forward B operand: k_adv_stats_idx lays it out in operand order (32 KB, L2-resident) and
@@ -104,6 +104,8 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
     unsigned long long st_last = 0;
 #endif
     __shared__ int s_next[2][2];                // per set, per iteration parity: does the set have a tile for the next iteration
+    __shared__ int s_first[2];                  // per set: is its first tile real
+    __shared__ int s_bar[2];                    // per set: arrivals at the set's own (software) barriers, free-running mode
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps set / net / cb and the phase switch scalar
@@ -262,6 +264,10 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
         t1 = base + 1;
         t2 = base + 2;
         if (lane == 0) t3_raw = (int)atomicAdd(tile_counter + zero_off, 1u);
+        if (lane == 0) {
+            s_first[set] = base < n_tiles ? 1 : 0;
+            s_bar[set] = 0;
+        }
         const int i0 = load_idx(base, st), i1 = load_idx(t1, st);
         n_idx = load_idx(t2, st);
         n_ok = n_idx >= 0;
@@ -275,21 +281,25 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
     float w1r[32];   // this wave's W1 slice for the next F1 (reloaded in B3: it only has to live from B3 to F1)
     load_w1(w1r, lane);
 
-    // Set 1 enters the tile loop a.skew barriers after set 0 and set 0 leaves it a.skew barriers before set 1:
-    // both sets run the same straight-line phase sequence, a.skew phases apart, on workgroup-wide barriers.
-    // A set whose queue has run dry while the other set still has a tile runs that iteration on all-padding rows:
-    // the indices are -1, so every row is zero, the loss lanes write zero gradients and the accumulators do not move.
 #ifdef AURPPO_MLP_STAMPS
     if (tid < 32) (&s_stamp[0][0])[tid] = 0ull;
     __syncthreads();
 #endif
-    if (set == 1) {
-        for (int k = 0; k < a.skew; ++k) __syncthreads();
-    }
-#ifdef AURPPO_MLP_STAMPS
-    st_last = __builtin_readcyclecounter();
-#endif
-    for (int it = 0;; ++it) {
+    // The two sets do not share barriers inside the tile loop.  A set's four waves meet at a counter in LDS (arrive =
+    // one ds_add by lane 0 once the wave's LDS writes have completed, wait = poll until 4 more arrivals than at the
+    // previous barrier), so neither set ever waits for the other's longer phase -- with workgroup-wide barriers 38 %
+    // of the loop was the tail of barrier intervals where one set finished its epilogue alone -- and a set whose
+    // queue is dry simply leaves.  s_barrier is only used before and after the loop.
+    int bar_gen = 0;
+    auto set_bar = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) (void)__hip_atomic_fetch_add(&s_bar[set], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        bar_gen += 4;
+        while (__hip_atomic_load(&s_bar[set], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - bar_gen < 0)
+            __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    for (int it = 0; s_first[set] != 0; ++it) {
         // Opaque per-tile copies of the lane coordinates: every LDS address below is re-derived from them inside
         // the phase (one or two VALU ops) instead of being hoisted out of the loop as ~100 loop-invariant
         // address registers that the allocator would then spill and reload in every phase.
@@ -326,7 +336,7 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
             if (w == 0 && sl == 0) s_next[set][it & 1] = t1 < n_tiles ? 1 : 0;   // t1 = tile of iteration it+1
         }
         STAMP2(0);
-        __syncthreads();
+        set_bar();
         STAMP2(8);
         {   // ---- F1: H1 = tanh(X W1^T + b1), B operand from registers
             f32x16 acc = zero16();
@@ -353,7 +363,7 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
             for (int e = 0; e < 16; ++e) sH1[(net * R + acc_row(e, ln)) * LD + col] = tanh_fast(acc[e] + bias);
         }
         STAMP2(1);
-        __syncthreads();
+        set_bar();
         STAMP2(9);
         {   // ---- F2
             f32x16 acc = zero16();
@@ -366,7 +376,7 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
             for (int e = 0; e < 16; ++e) sH2[(net * R + acc_row(e, ln)) * LD + col] = tanh_fast(acc[e] + bias);
         }
         STAMP2(2);
-        __syncthreads();
+        set_bar();
         STAMP2(10);
         {   // ---- F3: head (R x AP), each wave of a net takes 16 of the 32 rows
             const float* W = sW3 + net * AP * LD;
@@ -379,7 +389,7 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
             for (int e = 0; e < 4; ++e) sOut[(net * R + cb * 16 + 4 * (ln >> 4) + e) * LDO + col] = acc[e] + bias;
         }
         STAMP2(3);
-        __syncthreads();
+        set_bar();
         STAMP2(11);
         {   // ---- L: distribution + PPO terms, 8 lanes per row; head outputs become their gradients
             if (w == 0) {
@@ -451,7 +461,7 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
             }
         }
         STAMP2(4);
-        __syncthreads();
+        set_bar();
         STAMP2(12);
         {   // ---- B1: dH2 -> dZ2 (in place over this wave's half of H2), dW3
             const float* dO = sOut + net * R * LDO;
@@ -476,7 +486,7 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
             gb2 += colsum;
         }
         STAMP2(5);
-        __syncthreads();
+        set_bar();
         STAMP2(13);
         {   // ---- B2: dW2, dH1 -> dZ1 (in place over this wave's half of H1)
             const float* dZ = sH2 + net * R * LD;
@@ -502,7 +512,7 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
             gb1 += colsum;
         }
         STAMP2(6);
-        __syncthreads();
+        set_bar();
         STAMP2(14);
         {   // ---- B3: dW1 (two out-blocks x in-block cb of D)
             if (cb * 32 < D) {
@@ -515,14 +525,11 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
             load_w1(w1r, ln);
         }
         STAMP2(7);
-        __syncthreads();
+        set_bar();
         STAMP2(15);
-        // both sets see the same two flags (a slot is rewritten two iterations later), so they leave together
-        if (!(s_next[0][it & 1] | s_next[1][it & 1])) break;
+        if (!s_next[set][it & 1]) break;     // written by the set's wave 0 in this iteration's S phase
     }
-    if (set == 0) {
-        for (int k = 0; k < a.skew; ++k) __syncthreads();
-    }
+    __syncthreads();   // the hand-over below reuses the weights' LDS: both sets must have left the loop
 
     int le = lane, se = st;   // fresh opaque copies: nothing lane-derived has to stay live across the tile loop
     asm volatile("" : "+v"(le), "+v"(se));

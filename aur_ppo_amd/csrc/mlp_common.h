@@ -31,7 +31,6 @@ struct MlpArgs {
     float* slabs;          // (grid, n_params) per-workgroup gradient slabs
     double* loss_part;     // (grid, 8)
     unsigned long long* stamps;  // diagnostic build: (grid, 16) cycle counters
-    int skew;              // two-set kernel: phase offset between the sets (AURPPO_MLP_SKEW, default 3)
     unsigned* tile_counter;  // two-set kernel: next tile to hand out (zeroed by k_adv_stats_idx)
     float* w1op;           // two-set kernel: W1 slices in MFMA B-operand order, [4 waves][32 k-steps][64 lanes]
     const double* stats;   // (kStatBlocks, 2) advantage partial sums

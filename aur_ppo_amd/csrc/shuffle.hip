@@ -516,12 +516,30 @@ static double expected_draws(int n) {
 // sticky error flag instead of producing a wrong permutation.
 static double need_words(int n) { return expected_draws(n) + 12.0 * sqrt(2.0 * (double)n) + 2.0 * kMtN; }
 
+// k_mt_fill and k_fy_accept are single-workgroup latency chains that run side by side for most of an update.  The
+// dispatcher is free to put both on the same CU, where the 16 accept waves take four issue slots in five from the
+// twist (rocprof in-situ: k_mt_fill 640 us alone, 850-910 us next to the accept kernel).  Each therefore asks for
+// more than half a CU's LDS (unused), which no two of them can get together.
+constexpr size_t kOwnCuLds = 81 * 1024;
+static hipError_t own_cu_setup() {
+    static bool done = false;
+    if (done) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mt_fill), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)kOwnCuLds);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fy_accept<1024, 8>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kOwnCuLds);
+    done = e == hipSuccess;
+    return e;
+}
+
 static int enqueue_fill(aurppo_rng* rng, double need, hipStream_t after, int slot, int cur_slot) {
     // inventory target 2*need: one shuffle may be consuming while the next one's draws are produced
     AURPPO_HIP_TRY(hipEventRecord(rng->ev_sync, after));
     AURPPO_HIP_TRY(hipStreamWaitEvent(rng->fill_stream, rng->ev_sync, 0));
     const int nblk_max = (int)(2.0 * need / kMtN) + 2;
-    hipLaunchKernelGGL(k_mt_fill, dim3(1), dim3(kFillThreads), 0, rng->fill_stream, rng->d_last, rng->d_ring,
+    AURPPO_HIP_TRY(own_cu_setup());
+    hipLaunchKernelGGL(k_mt_fill, dim3(1), dim3(kFillThreads), kOwnCuLds, rng->fill_stream, rng->d_last, rng->d_ring,
                        (long long)rng->ring_cap, rng->d_pos, (long long)(2.0 * need), nblk_max, cur_slot);
     AURPPO_LAUNCH_CHECK("k_mt_fill");
     AURPPO_HIP_TRY(hipEventRecord(rng->ev_fill[slot], rng->fill_stream));
@@ -543,25 +561,9 @@ int permute_once(aurppo_rng* rng, const int32_t* in, int32_t* out, int n, hipStr
         rng->primed_need = need;
     }
     AURPPO_HIP_TRY(hipStreamWaitEvent(s, rng->ev_fill[slot], 0));
-    static int shape = -1;
-    if (shape < 0) {
-        const char* e = getenv("AURPPO_ACC_SHAPE");   // experiments only: threads * 100 + draws per thread
-        shape = e && *e ? atoi(e) : 102408;
-    }
-#define AURPPO_ACC_LAUNCH(T, W)                                                                                       \
-    hipLaunchKernelGGL((k_fy_accept<T, W>), dim3(1), dim3(T), 0, s, rng->d_ring, (long long)rng->ring_cap, rng->d_j, n, \
-                       rng->d_pos, 4 + slot)
-    switch (shape) {
-        case 25632: AURPPO_ACC_LAUNCH(256, 32); break;
-        case 25616: AURPPO_ACC_LAUNCH(256, 16); break;
-        case 51216: AURPPO_ACC_LAUNCH(512, 16); break;
-        case 51232: AURPPO_ACC_LAUNCH(512, 32); break;
-        case 102416: AURPPO_ACC_LAUNCH(1024, 16); break;
-        case 102432: AURPPO_ACC_LAUNCH(1024, 32); break;
-        case 51208: AURPPO_ACC_LAUNCH(512, 8); break;
-        default: AURPPO_ACC_LAUNCH(1024, 8);
-    }
-#undef AURPPO_ACC_LAUNCH
+    AURPPO_HIP_TRY(own_cu_setup());
+    hipLaunchKernelGGL((k_fy_accept<1024, 8>), dim3(1), dim3(1024), kOwnCuLds, s, rng->d_ring, (long long)rng->ring_cap,
+                       rng->d_j, n, rng->d_pos, 4 + slot);
     AURPPO_LAUNCH_CHECK("k_fy_accept");
     // Look-ahead: the NEXT shuffle's draws (assumed the same size) are twisted on the fill stream while
     // this shuffle's accept / link / resolve run here.  It is ordered after the PREVIOUS accept (ev_acc of
@@ -569,7 +571,7 @@ int permute_once(aurppo_rng* rng, const int32_t* in, int32_t* out, int n, hipStr
     if (rng->seq > 0) AURPPO_HIP_TRY(hipStreamWaitEvent(rng->fill_stream, rng->ev_acc[slot ^ 1], 0));
     {
         const int nblk_max = (int)(2.0 * need / kMtN) + 2;
-        hipLaunchKernelGGL(k_mt_fill, dim3(1), dim3(kFillThreads), 0, rng->fill_stream, rng->d_last, rng->d_ring,
+        hipLaunchKernelGGL(k_mt_fill, dim3(1), dim3(kFillThreads), kOwnCuLds, rng->fill_stream, rng->d_last, rng->d_ring,
                            (long long)rng->ring_cap, rng->d_pos, (long long)(2.0 * need), nblk_max,
                            rng->seq > 0 ? 4 + (slot ^ 1) : 1);   // cursor after the PREVIOUS shuffle (done: waited above)
         AURPPO_LAUNCH_CHECK("k_mt_fill");
