@@ -6,6 +6,7 @@
 
 struct AdamScalars {
     float coef;        // clip_grad_norm_ scale (<= 1, or NaN when the norm is NaN)
+    float gscale;      // applied to the stored gradient first (1/world after a SUM all-reduce; 1 otherwise)
     float step_size;   // lr / (1 - beta1^t)
     float bc2_sqrt;    // sqrt(1 - beta2^t)
     float w1, b2, w2, eps;
@@ -30,6 +31,7 @@ __device__ __forceinline__ AdamScalars adam_scalars(const double* __restrict__ p
     __syncthreads();
     AdamScalars a;
     a.coef = *s_coef;
+    a.gscale = 1.0f;
     const double tt = (double)*step;
     const double bc1 = 1.0 - pow(beta1, tt);
     const double bc2 = 1.0 - pow(beta2, tt);
@@ -43,12 +45,15 @@ __device__ __forceinline__ AdamScalars adam_scalars(const double* __restrict__ p
 }
 
 // m.lerp_(g, 1-b1); v = v*b2 + (1-b2)*g*g; p -= step_size * m / (sqrt(v)/sqrt(1-b2^t) + eps); returns the new p
+// store_g: leave the clipped gradient in g, as clip_grad_norm_ does (not when other workgroups of the same launch
+// are still reading g to form the norm)
 __device__ __forceinline__ float adam_update(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
-                                             float* __restrict__ v, int64_t i, bool clip, const AdamScalars& a) {
-    float gi = g[i];
+                                             float* __restrict__ v, int64_t i, bool clip, const AdamScalars& a,
+                                             bool store_g = true) {
+    float gi = g[i] * a.gscale;
     if (clip) {
         gi = gi * a.coef;
-        g[i] = gi;   // the clipped gradient stays visible, as clip_grad_norm_ leaves it
+        if (store_g) g[i] = gi;
     }
     const float mi = m[i] + a.w1 * (gi - m[i]);
     const float vi = v[i] * a.b2 + (a.w2 * gi) * gi;

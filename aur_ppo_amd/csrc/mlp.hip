@@ -602,7 +602,7 @@ constexpr size_t act_lds_bytes() {
 // 64 parameters x 16 slab groups per 1024-thread workgroup: every wave-instruction reads one coalesced
 // 256-B slab row, 16 rows per parameter are in flight at once, groups are combined through LDS in order.
 constexpr int kRedGroups = 16;
-// sq_part != nullptr (chained minibatch step): also the clip's partial sums of squares, one per workgroup, the Adam
+// sq_part != nullptr (chained minibatch step): also the clip's partial sums of squares, one per workgroup; step_dev != nullptr: the Adam
 // step count is advanced and the tile counter of the next K7 launch is cleared.
 __global__ __launch_bounds__(1024) void k_mlp_reduce(const float* __restrict__ slabs, const double* __restrict__ loss_part,
                                                      int n_slabs, int n_params, PpoHyper h, float* __restrict__ grads,
@@ -635,13 +635,11 @@ __global__ __launch_bounds__(1024) void k_mlp_reduce(const float* __restrict__ s
         }
         if (sq_part) {
             const double q = wave_sum((double)t * (double)t);
-            if (pi == 0) {
-                sq_part[blockIdx.x] = q;
-                if (blockIdx.x == 0) {
-                    *step_dev += 1.0f;   // the Adam kernel (next launch) reads the new step count
-                    *tile_counter = 0u;
-                }
-            }
+            if (pi == 0) sq_part[blockIdx.x] = q;
+        }
+        if (step_dev && pi == 0 && blockIdx.x == 0) {
+            *step_dev += 1.0f;   // the Adam kernel (a later launch) reads the new step count
+            *tile_counter = 0u;
         }
     }
     __shared__ double r[6];
@@ -677,17 +675,31 @@ __global__ __launch_bounds__(kThreads) void k_adam_chain(float* __restrict__ p, 
                                                          float* __restrict__ v, int n, const double* __restrict__ part,
                                                          int n_part, float max_norm, const float* __restrict__ lr_dev,
                                                          const float* __restrict__ step, double beta1, double beta2,
-                                                         double eps, float* __restrict__ out_norm, int nb_upd, int w1_actor,
-                                                         int w1_critic, int D, float* __restrict__ w1op,
+                                                         double eps, float* __restrict__ out_norm, float gscale, int nb_upd,
+                                                         int w1_actor, int w1_critic, int D, float* __restrict__ w1op,
                                                          const float4* __restrict__ rec, const int32_t* __restrict__ next_idx,
                                                          int next_M, double (*__restrict__ stats)[2]) {
     __shared__ double sc[2][kThreads / kWave];
     __shared__ float s_coef;
     if ((int)blockIdx.x < nb_upd) {
-        const AdamScalars a = adam_scalars<kThreads / kWave>(part, n_part, max_norm, lr_dev, step, beta1, beta2, eps, out_norm,
-                                                             blockIdx.x == 0, sc[0], &s_coef);
+        __shared__ double s_own;
+        if (!part) {
+            // no partial sums were left by k_mlp_reduce (the gradient went through an all-reduce since): every
+            // workgroup forms the norm of the scaled gradient itself, in the same order -- 17 k floats, L2-resident
+            double q = 0.0;
+            for (int i = threadIdx.x; i < n; i += kThreads) {
+                const double x = (double)(g[i] * gscale);
+                q += x * x;
+            }
+            const double t = block_sum<kThreads / kWave>(q, sc[1]);
+            if (threadIdx.x == 0) s_own = t;
+            __syncthreads();
+        }
+        AdamScalars a = adam_scalars<kThreads / kWave>(part ? part : &s_own, part ? n_part : 1, max_norm, lr_dev, step, beta1,
+                                                       beta2, eps, out_norm, blockIdx.x == 0, sc[0], &s_coef);
+        a.gscale = gscale;
         for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += nb_upd * kThreads) {
-            const float pn = adam_update(p, g, m, v, i, true, a);
+            const float pn = adam_update(p, g, m, v, i, true, a, part != nullptr);   // in-kernel norm: g is still being read
             const int ea = i - w1_actor, ec = i - w1_critic;
             const int e = (ea >= 0 && ea < H * D) ? ea : ((ec >= 0 && ec < H * D) ? ec : -1);
             if (e >= 0) {
@@ -740,7 +752,30 @@ struct ChainArgs {   // the optimizer half of aurppo_mlp_ppo_minibatch_f32
     const int32_t* next_idx;
     int next_M;
     int chained;
+    int grad_only;   // stop after k_mlp_reduce (the caller all-reduces the gradient, then calls the apply half)
 };
+struct WsView {   // carve-up of the caller's workspace (aurppo_mlp_workspace_bytes)
+    double* stats;               // (kStatBlocks, 2) advantage partial sums of the prepared minibatch
+    double* loss_part;           // (kMaxGrid, 8)
+    float* slabs;                // (kMaxGrid, n_params)
+    unsigned long long* stamps;  // diagnostic build
+    float* w1op;                 // W1 in B-operand order
+    unsigned* tile_counter;
+    double* sq_part;             // clip partial sums, one per k_mlp_reduce workgroup
+};
+WsView ws_view(void* workspace, int n_params) {
+    WsView v;
+    char* w = reinterpret_cast<char*>(workspace);
+    v.stats = reinterpret_cast<double*>(w);
+    v.loss_part = v.stats + 2 * kStatBlocks;
+    v.slabs = reinterpret_cast<float*>(v.loss_part + 8 * kMaxGrid);
+    v.stamps = reinterpret_cast<unsigned long long*>(w + ((sizeof(double) * (2 * kStatBlocks + 8 * kMaxGrid) +
+                                                           sizeof(float) * (size_t)kMaxGrid * (size_t)n_params + 63) / 64) * 64);
+    v.w1op = reinterpret_cast<float*>(v.stamps + 32 * kMaxGrid);
+    v.tile_counter = reinterpret_cast<unsigned*>(v.w1op + 4 * 32 * 64);
+    v.sq_part = reinterpret_cast<double*>(v.tile_counter + 16);
+    return v;
+}
 int stat_blocks_for(int M) {
     int sb = (M + kThreads * 4 - 1) / (kThreads * 4);
     return sb > kStatBlocks ? kStatBlocks : sb;
@@ -775,21 +810,20 @@ static int mlp_step_impl(const float* obs, const float* actions, const float* re
     for (int k = 0; k < (continuous ? 13 : 12); ++k)
         AURPPO_REQUIRE(layout_h[k] >= 0 && layout_h[k] < n_params, AURPPO_ESHAPE, "aurppo_mlp_ppo_step_f32: layout[%d]=%d", k, layout_h[k]);
     a.h = make_hyper(M, clip, ent_coef, vf_coef, norm_adv, vloss_mode);
-    char* w = reinterpret_cast<char*>(workspace);
-    double* stats = reinterpret_cast<double*>(w);
-    a.stats = stats;
-    a.loss_part = stats + 2 * kStatBlocks;
-    a.slabs = reinterpret_cast<float*>(a.loss_part + 8 * kMaxGrid);
-    a.stamps = reinterpret_cast<unsigned long long*>(w + ((sizeof(double) * (2 * kStatBlocks + 8 * kMaxGrid) +
-                                                            sizeof(float) * (size_t)kMaxGrid * (size_t)n_params + 63) / 64) * 64);
+    const WsView wv = ws_view(workspace, n_params);
+    double* stats = wv.stats;
+    a.stats = wv.stats;
+    a.loss_part = wv.loss_part;
+    a.slabs = wv.slabs;
+    a.stamps = wv.stamps;
     hipStream_t s = (hipStream_t)stream;
     const int sb = stat_blocks_for(M);
     a.n_stat_blocks = sb;
     const char* ve = getenv("AURPPO_MLP_VARIANT");   // read per call so that a test can run both variants in one process
     const int variant = (ve && *ve == '1') ? 1 : 2;
-    a.w1op = reinterpret_cast<float*>(a.stamps + 32 * kMaxGrid);
-    a.tile_counter = reinterpret_cast<unsigned*>(a.w1op + 4 * 32 * 64);
-    double* sq_part = reinterpret_cast<double*>(a.tile_counter + 16);
+    a.w1op = wv.w1op;
+    a.tile_counter = wv.tile_counter;
+    double* sq_part = wv.sq_part;
     if (!(chain && chain->chained)) {   // otherwise the previous chained call has prepared all of this
         hipLaunchKernelGGL(k_adv_stats_idx, dim3(sb), dim3(kThreads), 0, s, a.rec, idx, M,
                            reinterpret_cast<double (*)[2]>(stats), params, a.L.w1[0], a.L.w1[1], D,
@@ -838,15 +872,16 @@ static int mlp_step_impl(const float* obs, const float* actions, const float* re
     if (ev_end) AURPPO_HIP_TRY(hipEventRecord((hipEvent_t)ev_end, s));
     const int n_red = (n_params + 63) / 64;
     hipLaunchKernelGGL(k_mlp_reduce, dim3(n_red), dim3(1024), 0, s, a.slabs, a.loss_part, grid, n_params, a.h, grads,
-                       out_scalars, chain ? sq_part : nullptr, chain ? chain->step_dev : nullptr, a.tile_counter);
+                       out_scalars, (chain && !chain->grad_only) ? sq_part : nullptr, chain ? chain->step_dev : nullptr,
+                       a.tile_counter);
     AURPPO_LAUNCH_CHECK("k_mlp_reduce");
-    if (chain) {
+    if (chain && !chain->grad_only) {
         int nb_upd = (n_params + kThreads * 4 - 1) / (kThreads * 4);
         if (nb_upd > 64) nb_upd = 64;
         const int nsb = chain->next_idx ? stat_blocks_for(chain->next_M) : 0;
         hipLaunchKernelGGL(k_adam_chain, dim3(nb_upd + nsb), dim3(kThreads), 0, s, chain->params_rw, grads, chain->exp_avg,
                            chain->exp_avg_sq, n_params, sq_part, n_red, (float)chain->max_norm, chain->lr_dev,
-                           chain->step_dev, chain->beta1, chain->beta2, chain->eps, chain->out_norm, nb_upd, a.L.w1[0],
+                           chain->step_dev, chain->beta1, chain->beta2, chain->eps, chain->out_norm, 1.0f, nb_upd, a.L.w1[0],
                            a.L.w1[1], D, a.w1op, a.rec, chain->next_idx, chain->next_M,
                            reinterpret_cast<double (*)[2]>(stats));
         AURPPO_LAUNCH_CHECK("k_adam_chain");
@@ -884,9 +919,49 @@ extern "C" int aurppo_mlp_ppo_minibatch_f32(const float* obs, const float* actio
     ChainArgs c;
     c.params_rw = params; c.exp_avg = exp_avg; c.exp_avg_sq = exp_avg_sq; c.max_norm = max_norm; c.lr_dev = lr_dev;
     c.step_dev = step_dev; c.beta1 = beta1; c.beta2 = beta2; c.eps = eps; c.out_norm = out_norm;
-    c.next_idx = next_idx; c.next_M = next_idx ? next_M : 0; c.chained = chained ? 1 : 0;
+    c.next_idx = next_idx; c.next_M = next_idx ? next_M : 0; c.chained = chained ? 1 : 0; c.grad_only = 0;
     return mlp_step_impl(obs, actions, rec, idx, M, D, A, continuous, hidden, params, layout_h, n_params, grads, clip, ent_coef,
                          vf_coef, norm_adv, vloss_mode, out_scalars, workspace, stream, nullptr, nullptr, &c);
+}
+
+extern "C" int aurppo_mlp_ppo_grad_f32(const float* obs, const float* actions, const float* rec, const int32_t* idx, int M, int D,
+                                       int A, int continuous, int hidden, const float* params, const int* layout_h, int n_params,
+                                       float* grads, double clip, double ent_coef, double vf_coef, int norm_adv, int vloss_mode,
+                                       float* out_scalars, float* step_dev, int chained, void* workspace, void* stream) {
+    AURPPO_REQUIRE(step_dev, AURPPO_EINVAL, "aurppo_mlp_ppo_grad_f32: null step_dev");
+    ChainArgs c = {};
+    c.step_dev = step_dev; c.chained = chained ? 1 : 0; c.grad_only = 1;
+    return mlp_step_impl(obs, actions, rec, idx, M, D, A, continuous, hidden, params, layout_h, n_params, grads, clip, ent_coef,
+                         vf_coef, norm_adv, vloss_mode, out_scalars, workspace, stream, nullptr, nullptr, &c);
+}
+
+extern "C" int aurppo_mlp_ppo_apply_f32(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const int* layout_h,
+                                        int n_params, int D, double grad_scale, double max_norm, const float* lr_dev,
+                                        const float* step_dev, double beta1, double beta2, double eps, float* out_norm,
+                                        const float* rec, const int32_t* next_idx, int next_M, void* workspace, void* stream) {
+    AURPPO_REQUIRE(params && grads && exp_avg && exp_avg_sq && layout_h && lr_dev && step_dev && out_norm && workspace,
+                   AURPPO_EINVAL, "aurppo_mlp_ppo_apply_f32: null pointer");
+    AURPPO_REQUIRE(n_params > 0 && D >= 2 && D <= H && D % 2 == 0, AURPPO_ESHAPE, "aurppo_mlp_ppo_apply_f32: n_params=%d D=%d",
+                   n_params, D);
+    AURPPO_REQUIRE(!next_idx || (next_M > 0 && rec), AURPPO_ESHAPE, "aurppo_mlp_ppo_apply_f32: next_M=%d", next_M);
+    AURPPO_REQUIRE(aligned_to(workspace, 16) && (!rec || aligned_to(rec, 16)), AURPPO_EINVAL,
+                   "aurppo_mlp_ppo_apply_f32: workspace / rec not 16-byte aligned");
+    for (int k = 0; k < 12; ++k)
+        AURPPO_REQUIRE(layout_h[k] >= 0 && layout_h[k] < n_params, AURPPO_ESHAPE, "aurppo_mlp_ppo_apply_f32: layout[%d]=%d", k,
+                       layout_h[k]);
+    const WsView wv = ws_view(workspace, n_params);
+    double* stats = wv.stats;
+    float* w1op = wv.w1op;
+    int nb_upd = (n_params + kThreads * 4 - 1) / (kThreads * 4);
+    if (nb_upd > 64) nb_upd = 64;
+    const int nsb = next_idx ? stat_blocks_for(next_M) : 0;
+    hipLaunchKernelGGL(k_adam_chain, dim3(nb_upd + nsb), dim3(kThreads), 0, (hipStream_t)stream, params, grads, exp_avg,
+                       exp_avg_sq, n_params, (const double*)nullptr, 0, (float)max_norm, lr_dev, step_dev, beta1, beta2, eps,
+                       out_norm, (float)grad_scale, nb_upd, layout_h[0], layout_h[6], D, w1op,
+                       reinterpret_cast<const float4*>(rec), next_idx, next_idx ? next_M : 0,
+                       reinterpret_cast<double (*)[2]>(stats));
+    AURPPO_LAUNCH_CHECK("k_adam_chain");
+    return AURPPO_OK;
 }
 
 extern "C" int aurppo_mlp_act_f32(const float* obs, const float* noise, int N, int D, int A, int continuous, int hidden,

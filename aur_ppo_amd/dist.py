@@ -63,6 +63,14 @@ def allreduce_mean_(flat, world=None):
     return flat
 
 
+def allreduce_sum_(flat, world=None):
+    """In-place SUM over ranks; the caller folds the 1/W into its next kernel (``hip_ops.mlp_ppo_apply``)."""
+    w = world_size() if world is None else world
+    if w > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    return flat
+
+
 def barrier():
     if world_size() > 1:
         dist.barrier()

@@ -363,6 +363,42 @@ def mlp_ppo_minibatch(obs, actions, rec, idx, flat_param, layout, flat_grad, cli
     return out_scalars
 
 
+def mlp_ppo_grad(obs, actions, rec, idx, flat_param, layout, flat_grad, clip, ent_coef, vf_coef, norm_adv, vloss_mode,
+                 out_scalars, step_dev, chained=False):
+    """First half of a minibatch for one process per GPU: K7 + slab reduce into ``flat_grad[:n_params]`` (as
+    ``mlp_ppo_step``), the Adam step count advanced.  The caller all-reduces ``flat_grad`` and calls ``mlp_ppo_apply``."""
+    lib = _lib_or_raise()
+    M, D, A, n = idx.numel(), layout["D"], layout["A"], layout["n_params"]
+    cont = layout.get("continuous", True)
+    if obs.shape[-1] != D or actions.numel() != obs.shape[0] * (A if cont else 1) or rec.numel() != obs.shape[0] * 4:
+        raise ValueError("mlp_ppo_grad: buffer shapes do not match the policy")
+    ws = _workspace("mlp", lib.aurppo_mlp_workspace_bytes(n), obs.device)
+    lay = (C.c_int * 13)(*layout["offsets"])
+    _check(lib.aurppo_mlp_ppo_grad_f32(
+        _ptr(obs), _ptr(actions), _ptr(rec), _ptr(idx, torch.int32), M, D, A, int(cont), MLP_HIDDEN, _ptr(flat_param), lay, n,
+        _ptr(flat_grad), float(clip), float(ent_coef), float(vf_coef), int(bool(norm_adv)), int(vloss_mode), _ptr(out_scalars),
+        _ptr(step_dev), int(bool(chained)), C.c_void_p(ws.data_ptr()), _stream()), "aurppo_mlp_ppo_grad_f32")
+    return out_scalars
+
+
+def mlp_ppo_apply(flat_param, flat_grad, exp_avg, exp_avg_sq, layout, lr_dev, step_dev, max_norm, betas, eps, out_norm,
+                  grad_scale=1.0, rec=None, next_idx=None):
+    """Second half: ``flat_grad *= grad_scale`` (1/world after a SUM all-reduce), ``clip_grad_norm_`` and ``Adam.step`` in
+    one launch, which also prepares ``next_idx`` for the next ``mlp_ppo_grad(..., chained=True)``."""
+    lib = _lib_or_raise()
+    n = layout["n_params"]
+    if min(flat_param.numel(), flat_grad.numel(), exp_avg.numel(), exp_avg_sq.numel()) < n:
+        raise ValueError("mlp_ppo_apply: the flat bucket is smaller than the policy")
+    ws = _workspace("mlp", lib.aurppo_mlp_workspace_bytes(n), flat_param.device)
+    lay = (C.c_int * 13)(*layout["offsets"])
+    _check(lib.aurppo_mlp_ppo_apply_f32(
+        _ptr(flat_param), _ptr(flat_grad), _ptr(exp_avg), _ptr(exp_avg_sq), lay, n, layout["D"], float(grad_scale), float(max_norm),
+        _ptr(lr_dev), _ptr(step_dev), float(betas[0]), float(betas[1]), float(eps), _ptr(out_norm),
+        _ptr(rec) if rec is not None else None, _ptr(next_idx, torch.int32) if next_idx is not None else None,
+        int(next_idx.numel()) if next_idx is not None else 0, C.c_void_p(ws.data_ptr()), _stream()), "aurppo_mlp_ppo_apply_f32")
+    return out_norm
+
+
 def mlp_act(obs, noise, flat_param, layout, actions=None, logp=None, value=None):
     """K8: the rollout step of the MLP actor-critic in one launch.  ``noise``: (N,A) standard-normal draws
     (Gaussian head) or (N,) uniform draws (Categorical head); None -> value only.  Outputs may be rows of

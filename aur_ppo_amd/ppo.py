@@ -357,12 +357,16 @@ class ppo:
         # launches per minibatch (each call also prepares the statistics of the slice that follows it)
         chain = (packed and self._mlp is not None and self.world == 1 and self._fused_adam
                  and self._bucket_is_policy and hasattr(ops, "mlp_ppo_minibatch"))
+        # one process per GPU: the same chain in two halves around the gradient all-reduce (SUM; the 1/W rides in the
+        # apply kernel), three launches + one collective per minibatch
+        chain_dp = (packed and self._mlp is not None and self.world > 1 and self._fused_adam
+                    and self._bucket_is_policy and hasattr(ops, "mlp_ppo_grad"))
         starts = list(range(0, B, M))
         for ep in range(self.num_update_epochs):
             idx_ep = perms[ep]
             for si, start in enumerate(starts):
                 mb_inds = idx_ep[start:start + M]
-                if chain:
+                if chain or chain_dp:
                     if si + 1 < len(starts):
                         nxt = idx_ep[starts[si + 1]:starts[si + 1] + M]
                     elif ep + 1 < self.num_update_epochs:
@@ -370,6 +374,16 @@ class ppo:
                     else:
                         nxt = None
                     g = self.optimizer.param_groups[0]
+                if chain_dp:
+                    ops.mlp_ppo_grad(b_obs, b_actions, self._rec, mb_inds, self.bucket.flat_param, self._mlp,
+                                     self.bucket.flat_grad, self.clip_coeff, self.entropy_coeff, self.value_coeff,
+                                     self.norm_adv, vmode, self._scalars[step], self._adam_t, chained=step > 0)
+                    D.allreduce_sum_(self.bucket.flat_grad, self.world)
+                    ops.mlp_ppo_apply(self.bucket.flat_param, self.bucket.flat_grad, self._adam_m, self._adam_v, self._mlp,
+                                      self._lr_tensor, self._adam_t, self.max_grad_norm, g["betas"], g["eps"],
+                                      self._norms[step:step + 1], grad_scale=1.0 / self.world, rec=self._rec, next_idx=nxt)
+                    step += 1
+                    continue
                     ops.mlp_ppo_minibatch(b_obs, b_actions, self._rec, mb_inds, self.bucket.flat_param, self._mlp,
                                           self.bucket.flat_grad, self.clip_coeff, self.entropy_coeff, self.value_coeff,
                                           self.norm_adv, vmode, self._scalars[step], self._adam_m, self._adam_v,

@@ -188,6 +188,23 @@ int aurppo_mlp_ppo_minibatch_f32(const float* obs, const float* actions, const f
                                  double beta1, double beta2, double eps, float* out_norm, const int32_t* next_idx,
                                  int next_M, int chained, void* workspace, void* stream);
 
+/* The same minibatch in two halves, for one process per GPU (src/ppo.py:219-269 with a gradient all-reduce between
+ * loss.backward() and clip_grad_norm_): aurppo_mlp_ppo_grad_f32 = aurppo_mlp_ppo_step_f32 that also advances the Adam
+ * step count (step_dev) and, with chained != 0, skips the preparation the previous apply call already did;
+ * aurppo_mlp_ppo_apply_f32 = clip_grad_norm_ + Adam over the bucket in ONE launch: the stored gradient is first
+ * multiplied by grad_scale (1/world after a SUM all-reduce), its norm is formed inside the kernel (grads itself is
+ * left as it was: other workgroups are still reading it), and -- as in
+ * aurppo_mlp_ppo_minibatch_f32 -- the statistics of next_idx and the operand copy of the new first layer are
+ * prepared for the next aurppo_mlp_ppo_grad_f32(chained = 1) on this workspace.                               */
+int aurppo_mlp_ppo_grad_f32(const float* obs, const float* actions, const float* rec, const int32_t* idx, int M, int D,
+                            int A, int continuous, int hidden, const float* params, const int* layout_h, int n_params,
+                            float* grads, double clip, double ent_coef, double vf_coef, int norm_adv, int vloss_mode,
+                            float* out_scalars, float* step_dev, int chained, void* workspace, void* stream);
+int aurppo_mlp_ppo_apply_f32(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const int* layout_h,
+                             int n_params, int D, double grad_scale, double max_norm, const float* lr_dev,
+                             const float* step_dev, double beta1, double beta2, double eps, float* out_norm,
+                             const float* rec, const int32_t* next_idx, int next_M, void* workspace, void* stream);
+
 /* ---- K8: rollout step for the MLP actor-critic -----------------------------------------------------
  * Replaces `action, logprob, _, value = policy.evaluate(next_obs)` under no_grad and the three buffer row
  * stores that follow it (src/ppo.py:104-108), and with noise == NULL the bootstrap `policy.value(next_obs)`

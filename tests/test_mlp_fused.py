@@ -205,3 +205,40 @@ def test_chained_minibatches_match_step_then_clip_adam(cont, variant):
     for a_, b_ in zip(got[:3], ref[:3]):
         torch.testing.assert_close(a_, b_, rtol=1e-4, atol=1e-6)
     assert float((ref[0] - p0).abs().max()) > 1e-3      # the run did move the parameters
+
+
+def test_grad_and_apply_halves_match_the_whole_minibatch(variant):
+    """aurppo_mlp_ppo_grad_f32 -> (an all-reduce's SUM, emulated by doubling) -> aurppo_mlp_ppo_apply_f32(grad_scale = 1/2)
+    over a run of chained minibatches == aurppo_mlp_ppo_minibatch_f32 over the same run."""
+    T, N, D, A, M = 16, 64, 64, 6, 300
+    H, pol, bucket, obs, act, rec = _setup(T, N, D, A, seed=4, cont=True)
+    lay = H.mlp_layout(pol, bucket)
+    n, nb = lay["n_params"], bucket.flat_param.numel()
+    perm = torch.randperm(T * N, device="cuda").int()
+    slices = [perm[s:s + M] for s in range(0, T * N, M)]
+    p0 = bucket.flat_param.clone()
+
+    def run(split):
+        bucket.flat_param.copy_(p0)
+        m, v, g = (torch.zeros(nb, device="cuda") for _ in range(3))
+        lr, t = torch.full((1,), 3e-3, device="cuda"), torch.zeros(1, device="cuda")
+        sc, norms = torch.zeros(len(slices), 9, device="cuda"), torch.zeros(len(slices), device="cuda")
+        for k, idx in enumerate(slices):
+            nxt = slices[k + 1] if k + 1 < len(slices) else None
+            if split:
+                H.mlp_ppo_grad(obs, act, rec, idx, bucket.flat_param, lay, g, 0.2, 0.01, 0.5, True, 1, sc[k], t, chained=k > 0)
+                g.mul_(2.0)                                   # what a 2-rank SUM of identical shards would leave
+                H.mlp_ppo_apply(bucket.flat_param, g, m, v, lay, lr, t, 0.5, (0.9, 0.999), 1e-5, norms[k:k + 1], grad_scale=0.5,
+                                rec=rec, next_idx=nxt)
+            else:
+                H.mlp_ppo_minibatch(obs, act, rec, idx, bucket.flat_param, lay, g, 0.2, 0.01, 0.5, True, 1, sc[k], m, v, lr, t, 0.5,
+                                    (0.9, 0.999), 1e-5, norms[k:k + 1], next_idx=nxt, chained=k > 0)
+        torch.cuda.synchronize()
+        return bucket.flat_param.clone(), m, v, sc, norms, float(t)
+
+    ref, got = run(False), run(True)
+    assert got[5] == ref[5] == len(slices)
+    torch.testing.assert_close(got[4], ref[4], rtol=1e-6, atol=0)
+    torch.testing.assert_close(got[3], ref[3], rtol=1e-6, atol=1e-7)
+    for a_, b_ in zip(got[:3], ref[:3]):
+        torch.testing.assert_close(a_, b_, rtol=1e-5, atol=1e-7)
