@@ -143,8 +143,13 @@ def cpu_baseline(args, data, init_sd, n_updates):
 def main():
     args = parse()
     from aur_ppo_amd import dist as D
-    rank, local_rank, world = D.init_from_env()
+    # AURPPO_BENCH_REHEARSE=1: every rank on cuda:0 over gloo -- a rehearsal of the N > 1 code path on a one-GPU box
+    # (its timings mean nothing); the driver's runs use one device per rank over RCCL
+    rehearse = os.environ.get("AURPPO_BENCH_REHEARSE") == "1"
+    rank, local_rank, world = D.init_from_env(backend="gloo" if rehearse else None)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     from aur_ppo_amd.ppo import ppo
@@ -213,6 +218,9 @@ def main():
     M = agent.minibatch_size
 
     def pmc(name):
+        """PMC bytes per launch, collected (separate --pmc passes) on the default workload only."""
+        if (M, Dm, A) != (131072, 64, 6):
+            return None
         path = os.path.join(ROOT, "profiles", name)
         try:
             return json.load(open(path)).get("hbm_bytes_per_launch")
@@ -231,7 +239,8 @@ def main():
                     "flops_per_launch": flops, "avg_launch_us": round(ms * 1e3, 2), "launches_timed": len(mlp_events),
                     "algorithmic_hbm_bytes_per_launch": M * (4 * (Dm + A + 4) + 4),
                     "how": "hipEvent pair recorded inside the library around the K7 kernel, one extra stand-alone "
-                           "launch every 4th step on the update's own minibatch (the update itself is a hipGraph)"}
+                           "launch every 4th step on the update's own minibatch"
+                           + (" (the update itself is a hipGraph)" if agent._graph is not None else "")}
     elif probe.pairs:
         gather_bytes = M * (8 * Dm + 8 * A + 36)          # idx + 6 streams read + written
         g_ms = probe.mean_ms()
