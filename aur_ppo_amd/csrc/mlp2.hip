@@ -12,7 +12,7 @@
 //
 // What had to move to make two sets fit one CU (160 KB LDS, 256 VGPRs per wave at 2 waves/SIMD):
 //   * W1 is only ever a forward B operand: k_adv_stats_idx lays it out in operand order (32 KB, L2-resident) and
-//     each wave streams its 32x64 slice with coalesced loads one phase ahead of layer 1; W2 / W3 / biases stay in
+//     each wave streams its 32x64 slice with coalesced loads in B3 of the previous tile; W2 / W3 / biases stay in
 //     LDS once per workgroup and are shared by both sets;
 //   * dZ2 and dZ1 overwrite H2 and H1 in place (a wave only reads its own column half of them in the phase
 //     that produces the gradient), which removes the dZ buffer and one barrier per tile;
@@ -105,10 +105,10 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
 #endif
     __shared__ int s_next[2][2];                // per set, per iteration parity: does the set have a tile for the next iteration
     __shared__ int s_first[2];                  // per set: is its first tile real
-    __shared__ int s_bar[2];                    // per set: arrivals at the set's own (software) barriers, free-running mode
+    __shared__ int s_bar[2];                    // per set: arrivals at the set's own (software) barriers
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps set / net / cb and the phase switch scalar
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps set / net / cb and everything derived from them scalar
     const int set = wave >> 2, w = wave & 3, st = tid & (kSetThreads - 1);
     const int net = w >> 1, cb = w & 1;
     const int D = a.D, A = a.A;
