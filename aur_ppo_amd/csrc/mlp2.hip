@@ -131,6 +131,46 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
     int* sSrc = reinterpret_cast<int*>(base + pSrc);
     int* sIdx = reinterpret_cast<int*>(base + pIdx);
 
+    const int n_tiles = (a.h.M + R - 1) / R;
+    // Tiles are handed out dynamically (one global counter, reset by k_adv_stats_idx): a workgroup that starts
+    // late -- this kernel needs a whole CU's registers, so it waits for CUs that other streams' kernels occupy --
+    // or that shares its CU simply takes fewer tiles, instead of holding the whole launch back.
+    unsigned* const tile_counter = a.tile_counter;
+    // An opaque zero in the address keeps LLVM's atomic optimizer away from the grabs below: it would rewrite each
+    // one as a wave-wide scan + readfirstlane of the result, i.e. wait for the atomic's round trip on the spot,
+    // while the point of grabbing a tile ahead is that nobody waits for it.
+    int zero_off = 0;
+    asm volatile("" : "+v"(zero_off));
+    int n_idx = -1;
+    bool n_ok = false;
+    // Global loads below are branch-free (padding lanes read element 0 and discard it): straight-line code lets
+    // the compiler count outstanding loads exactly, so a wait for one load does not turn into a wait for all.
+    auto load_idx = [&](int tile, int st) -> int {   // wave 0 of the set; lanes >= R mirror lanes < R
+        const int m = tile * R + (st & (R - 1));
+        const bool ok = tile < n_tiles && m < a.h.M;
+        const int v = a.idx[ok ? m : 0];
+        return ok ? v : -1;
+    };
+    // wave 0 of each set owns the set's tile queue: t1 / t2 = tiles of the next two iterations (wave-uniform),
+    // t3_raw = lane 0's pending grab for the one after (an atomic issued one tile ahead of its use)
+    int t1 = 0, t2 = 0, t3_raw = 0;
+    // The first grab goes out before anything else (all sets hit one counter: ~a microsecond of round trip when
+    // 496 of them arrive together); its result is only looked at after the weights have been staged.
+    // Priming the queue (tiles of iterations 0..3).  Large minibatches: everything comes from the counter -- one grab
+    // of three consecutive tiles plus a single one -- so a workgroup that starts late owns nothing.  Small ones (under
+    // four tiles per set): a set's first two tiles are fixed (set s of S takes tiles s and s + S) and the counter
+    // starts behind them, because grabs issued back to back by one wave are served back to back and the few tiles
+    // there are would all land in the first sets to arrive (64 tiles on 64 sets took three rounds instead of one).
+    // Either way the grabs go out before anything else: all sets hit one counter, ~a microsecond of round trip when
+    // 496 of them arrive together, which the weight staging hides.
+    const int n_sets = 2 * gridDim.x, my_set = 2 * blockIdx.x + set;
+    const bool fixed_start = n_tiles < 4 * n_sets;
+    const int dyn_base = fixed_start ? 2 * n_sets : 0;   // tile = dyn_base + counter value
+    int g0_raw = 0;
+    if (w == 0 && lane == 0) {
+        g0_raw = (int)atomicAdd(tile_counter + zero_off, fixed_start ? 1u : 3u);
+        t3_raw = (int)atomicAdd(tile_counter + zero_off, 1u);
+    }
     // ---- stage the shared weights (once per launch)
     for (int n = 0; n < 2; ++n) {
         for (int e = tid; e < H * H; e += kThreads2) sW2[(n * H + e / H) * LD + e % H] = a.params[a.L.w2[n] + e];
@@ -152,6 +192,23 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
     }
     for (int e = st; e < R * LD; e += kSetThreads) sX[e] = 0.0f;   // columns >= D stay zero for the whole launch
     for (int e = tid; e < 2 * 6 * R; e += kThreads2) (&s_loss[0][0][0])[e] = 0.0;
+    if (w == 0) {
+        const int g0 = __builtin_amdgcn_readfirstlane(g0_raw);
+        const int base = fixed_start ? my_set : g0;
+        t1 = fixed_start ? my_set + n_sets : g0 + 1;
+        t2 = fixed_start ? dyn_base + g0 : g0 + 2;
+        if (lane == 0) {
+            s_first[set] = base < n_tiles ? 1 : 0;
+            s_bar[set] = 0;
+        }
+        const int i0 = load_idx(base, st), i1 = load_idx(t1, st);
+        n_idx = load_idx(t2, st);
+        n_ok = n_idx >= 0;
+        if (st < R) {
+            sIdx[st] = i0;
+            sIdx[R + st] = i1;
+        }
+    }
     // ---- minibatch advantage statistics from the partials (same order in every workgroup)
     {
         double s = 0.0, q = 0.0;
@@ -189,35 +246,13 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
     float g_b3a[2] = {0.0f, 0.0f}, g_ls[2] = {0.0f, 0.0f}, g_b3c = 0.0f;   // loss-lane (row, j) partial column sums
 
     const float* __restrict__ w1p = a.w1op + (size_t)w * 32 * kWave;
-    const int n_tiles = (a.h.M + R - 1) / R;
-    // Tiles are handed out dynamically (one global counter, reset by k_adv_stats_idx): a workgroup that starts
-    // late -- this kernel needs a whole CU's registers, so it waits for CUs that other streams' kernels occupy --
-    // or that shares its CU simply takes fewer tiles, instead of holding the whole launch back.
-    unsigned* const tile_counter = a.tile_counter;
-    // An opaque zero in the address keeps LLVM's atomic optimizer away from the grabs below: it would rewrite each
-    // one as a wave-wide scan + readfirstlane of the result, i.e. wait for the atomic's round trip on the spot,
-    // while the point of grabbing a tile ahead is that nobody waits for it.
-    int zero_off = 0;
-    asm volatile("" : "+v"(zero_off));
     const bool vec4 = (D % 4 == 0) && ((reinterpret_cast<size_t>(a.obs) & 15) == 0);
     // loss-lane coordinates, also the action staging slots: row lr = st >> 3, action dims lj = st & 7 and lj + 8
     float xr[8];            // next tile's observation elements, in flight
     float ar[2], act_cur[2] = {0.0f, 0.0f};
     float4 p_rec = make_float4(0.f, 0.f, 0.f, 0.f);
-    int p_src = -1, n_idx = -1;
-    bool n_ok = false;
+    int p_src = -1;
 
-    // Global loads below are branch-free (padding lanes read element 0 and discard it): straight-line code lets
-    // the compiler count outstanding loads exactly, so a wait for one load does not turn into a wait for all.
-    auto load_idx = [&](int tile, int st) -> int {   // wave 0 of the set; lanes >= R mirror lanes < R
-        const int m = tile * R + (st & (R - 1));
-        const bool ok = tile < n_tiles && m < a.h.M;
-        const int v = a.idx[ok ? m : 0];
-        return ok ? v : -1;
-    };
-    // wave 0 of each set owns the set's tile queue: t1 / t2 = tiles of the next two iterations (wave-uniform),
-    // t3_raw = lane 0's pending grab for the one after (an atomic issued one tile ahead of its use)
-    int t1 = 0, t2 = 0, t3_raw = 0;
     // Raw values only: padding lanes are zeroed when the tile is landed (S), because touching a loaded value
     // here would wait for it on the spot.
     bool x_ok[2] = {false, false}, a_ok[2] = {false, false};   // vec4: per 16-row pass; otherwise x_ok[0] = row is real
@@ -257,25 +292,6 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
 #pragma unroll
         for (int m = 0; m < 32; ++m) w1r[m] = w1p[m * kWave + ln];
     };
-    if (w == 0) {
-        int base = 0;
-        if (lane == 0) base = (int)atomicAdd(tile_counter, 3u);
-        base = __builtin_amdgcn_readfirstlane(base);
-        t1 = base + 1;
-        t2 = base + 2;
-        if (lane == 0) t3_raw = (int)atomicAdd(tile_counter + zero_off, 1u);
-        if (lane == 0) {
-            s_first[set] = base < n_tiles ? 1 : 0;
-            s_bar[set] = 0;
-        }
-        const int i0 = load_idx(base, st), i1 = load_idx(t1, st);
-        n_idx = load_idx(t2, st);
-        n_ok = n_idx >= 0;
-        if (st < R) {
-            sIdx[st] = i0;
-            sIdx[R + st] = i1;
-        }
-    }
     __syncthreads();
     prefetch(sIdx, st);
     float w1r[32];   // this wave's W1 slice for the next F1 (reloaded in B3: it only has to live from B3 to F1)
@@ -394,7 +410,7 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
         {   // ---- L: distribution + PPO terms, 8 lanes per row; head outputs become their gradients
             if (w == 0) {
                 // the grab issued one tile ago is tile it+3: fetch its indices (landed in LDS at the next S), grab again
-                const int t3 = __builtin_amdgcn_readfirstlane(t3_raw);
+                const int t3 = dyn_base + __builtin_amdgcn_readfirstlane(t3_raw);
                 if (ln == 0) t3_raw = (int)atomicAdd(tile_counter + zero_off, 1u);
                 // raw index now, validity applied when it is landed at the next S: touching the loaded value here
                 // would wait for it, and for the grab issued just above
