@@ -66,7 +66,7 @@ constexpr int pSrc = pRec + 4 * R;           // int[R]
 constexpr int pIdx = pSrc + R;               // int[2][R]
 constexpr int kSetFloats = pIdx + 2 * R;     // multiple of 4
 static_assert(kSharedFloats % 4 == 0 && pRec % 4 == 0 && kSetFloats % 4 == 0, "float4 alignment of sRec");
-constexpr int kAccRegs = 80;                 // gW1 (32) + gW2 (32) + gW3 (16) per lane
+constexpr int kAccRegs = 72;                 // gW1 (32) + gW2 (32) + gW3 (2 x 4) per lane
 static_assert(kSharedFloats + 2 * kSetFloats >= 4 * kAccRegs * kWave, "hand-over scratch must fit the dead tiles");
 
 // All-reduce over aligned groups of 8 lanes with DPP moves (no LDS traffic): lane i <- i ^ 7 (row_half_mirror),
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
     // ---- persistent accumulators (registers)
     f32x16 gW1[2] = {zero16(), zero16()};
     f32x16 gW2[2] = {zero16(), zero16()};
-    f32x16 gW3 = zero16();
+    f32x4 gW3[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // dW3 as two 16x16 blocks: rows = head outputs, cols cb*32 + 16*q + (lane & 15)
     float gb1 = 0.0f, gb2 = 0.0f;
     float g_b3a[2] = {0.0f, 0.0f}, g_ls[2] = {0.0f, 0.0f}, g_b3c = 0.0f;   // loss-lane (row, j) partial column sums
 
@@ -485,9 +485,12 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
             float* H2 = sH2 + net * R * LD;
             f32x16 acc = zero16();
             mma32<AP, kCh, true>(acc, [&](int i, int k) { return dO[i * LDO + k]; }, [&](int k, int j) { return W3[k * LD + cb * 32 + j]; }, ln);
-            // dW3 (rows < AP) x (in-block cb): A = dO^T, B = H2 (still the activations)
-            mma32<R, kCh, true>(gW3, [&](int i, int k) { return i < AP ? dO[k * LDO + i] : 0.0f; },
-                     [&](int k, int j) { return H2[k * LD + cb * 32 + j]; }, ln);
+            // dW3 (AP rows) x (in-block cb) as two 16x16 blocks: A = dO^T, B = H2 (still the activations) -- a 32x32 MFMA
+            // block would spend half its rows on padding
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                gW3[q] += mma16<R, true>([&](int i, int k) { return dO[k * LDO + i]; },
+                                         [&](int k, int j) { return H2[k * LD + cb * 32 + 16 * q + j]; }, ln);
             const int col = cb * 32 + (ln & 31);
             float colsum = 0.0f;
 #pragma unroll
@@ -570,7 +573,11 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
             park[(16 + e) * kWave] = gW1[1][e];
             park[(32 + e) * kWave] = gW2[0][e];
             park[(48 + e) * kWave] = gW2[1][e];
-            park[(64 + e) * kWave] = gW3[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            park[(64 + e) * kWave] = gW3[0][e];
+            park[(68 + e) * kWave] = gW3[1][e];
         }
         if (le < 32) {
             s_gb[w][0][le] = gb1;
@@ -591,9 +598,12 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
             }
         }
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int o = acc_row(e, le);
-            if (o < out_dim[net]) slab[a.L.w3[net] + o * H + col] = gW3[e] + park[(64 + e) * kWave];
+        for (int e = 0; e < 4; ++e) {
+            const int o = 4 * (le >> 4) + e, c = cb * 32 + (le & 15);   // 16x16 accumulator layout
+            if (o < out_dim[net]) {
+                slab[a.L.w3[net] + o * H + c] = gW3[0][e] + park[(64 + e) * kWave];
+                slab[a.L.w3[net] + o * H + c + 16] = gW3[1][e] + park[(68 + e) * kWave];
+            }
         }
         if (le < 32) {
             slab[a.L.b1[net] + col] = gb1 + s_gb[w][0][le];
