@@ -300,6 +300,8 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
 #ifdef AURPPO_MLP_STAMPS
     if (tid < 32) (&s_stamp[0][0])[tid] = 0ull;
     __syncthreads();
+    st_last = __builtin_readcyclecounter();
+    const unsigned long long clk0 = st_last, rt0 = wall_clock64();   // shader cycles vs the 100 MHz wall clock
 #endif
     // The two sets do not share barriers inside the tile loop.  A set's four waves meet at a counter in LDS (arrive =
     // one ds_add by lane 0 once the wave's LDS writes have completed, wait = poll until 4 more arrivals than at the
@@ -643,7 +645,11 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
     }
 #ifdef AURPPO_MLP_STAMPS
     __syncthreads();
-    if (tid < 32) a.stamps[(size_t)blockIdx.x * 32 + tid] = (&s_stamp[0][0])[tid];
+    if (tid < 32) a.stamps[(size_t)blockIdx.x * 40 + tid] = (&s_stamp[0][0])[tid];
+    if (tid == 0) {   // shader cycles and 100 MHz wall-clock ticks of the tile loop + hand-over: the clock the launch ran at
+        a.stamps[(size_t)blockIdx.x * 40 + 32] = __builtin_readcyclecounter() - clk0;
+        a.stamps[(size_t)blockIdx.x * 40 + 33] = wall_clock64() - rt0;
+    }
 #endif
 }
 

@@ -38,8 +38,11 @@ if variant == "1":
         print(f"{nm:24s} {med[k]:12.0f} cycles  {100 * med[k] / tot:5.1f} %")
     print("total cycles (wave 0, median WG):", tot, " tiles per WG:", M // 32 // 256)
 else:
-    st = ws[off:off + 8 * 32 * 256].view(torch.int64).view(256, 2, 16).cpu().numpy().astype(np.float64)
-    st = st[st[:, 0, 1] > 0]
+    raw = ws[off:off + 8 * 40 * 256].view(torch.int64).view(256, 40).cpu().numpy().astype(np.float64)
+    raw = raw[raw[:, 1] > 0]
+    cyc, ticks = np.median(raw[:, 32]), np.median(raw[:, 33])
+    print(f"shader clock over the tile loop + hand-over: {cyc:.0f} cycles in {ticks:.0f} ticks of the 100 MHz wall clock = {cyc / ticks * 0.1:.2f} GHz")
+    st = raw[:, :32].reshape(-1, 2, 16)
     names = ["S  land tile, prefetch", "F1 layer 1 + tanh", "F2 layer 2 + tanh", "F3 head", "L  loss lanes", "B1 dH2,dW3,dZ2",
              "B2 dW2,dH1,dZ1", "B3 dW1"]
     med = np.median(st, axis=0)     # (2, 16)
