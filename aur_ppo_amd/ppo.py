@@ -384,6 +384,7 @@ class ppo:
                                       self._norms[step:step + 1], grad_scale=1.0 / self.world, rec=self._rec, next_idx=nxt)
                     step += 1
                     continue
+                if chain:
                     ops.mlp_ppo_minibatch(b_obs, b_actions, self._rec, mb_inds, self.bucket.flat_param, self._mlp,
                                           self.bucket.flat_grad, self.clip_coeff, self.entropy_coeff, self.value_coeff,
                                           self.norm_adv, vmode, self._scalars[step], self._adam_m, self._adam_v,

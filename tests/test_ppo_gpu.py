@@ -168,3 +168,35 @@ def test_graph_replay_matches_eager_update():
         outs.append((torch.stack(sc), agent.bucket.flat_param.clone()))
     torch.testing.assert_close(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-7)
+
+
+def test_single_process_update_takes_the_chained_entry_point(monkeypatch):
+    """Which native path the trainer takes is part of what is benchmarked: an MLP policy in one process must go
+    through aurppo_mlp_ppo_minibatch_f32 (three launches per minibatch), once per minibatch, and nothing else."""
+    from aur_ppo_amd import hip_ops as H
+    calls = {"minibatch": 0, "step": 0, "clip_adam": 0}
+    real = {k: getattr(H, k) for k in ("mlp_ppo_minibatch", "mlp_ppo_step", "clip_adam_")}
+
+    def spy(name, key):
+        def f(*a, **kw):
+            calls[key] += 1
+            return real[name](*a, **kw)
+        return f
+    monkeypatch.setattr(H, "mlp_ppo_minibatch", spy("mlp_ppo_minibatch", "minibatch"))
+    monkeypatch.setattr(H, "mlp_ppo_step", spy("mlp_ppo_step", "step"))
+    monkeypatch.setattr(H, "clip_adam_", spy("clip_adam_", "clip_adam"))
+    hp = dict(gym_id="Synthetic-v0", seed=1.0, num_steps=16, gae=True, total_timesteps=16 * 64 * 2, anneal_lr=True,
+              gae_lambda=0.95, num_update_epochs=3, num_envs=64, num_minibatches=4, entropy_coeff=0.0, value_coeff=0.5,
+              clip_coeff=0.2, clip_vloss=True, max_grad_norm=0.5, target_kl=None, norm_adv=True, capture_video=False,
+              hidden_dim=64, continuous=True, learning_rate=3e-4, exp_name="t", num_layers=2, dropout=0.0, gamma=0.99,
+              track=False, log=False, save=False, obs_dim=16, act_dim=3, hip_graph=False)
+    agent = _agent(hp)
+    assert agent._mlp is not None and agent._bucket_is_policy and agent._fused_adam
+    roll = synth_rollout(16, 64, 16, 3, continuous=True, seed=5)
+    for k in ("states", "actions", "log_probs", "rewards", "terminals", "values"):
+        getattr(agent.buffer, k).copy_(torch.from_numpy(roll[k]))
+    ret, adv = agent.advantages(torch.from_numpy(roll["next_obs"]).cuda(), torch.from_numpy(roll["next_done"]).cuda())
+    n = agent.update(ret, adv)
+    torch.cuda.synchronize()
+    assert n == 12 and calls == {"minibatch": 12, "step": 0, "clip_adam": 0}
+    assert float(agent._adam_t) == 12.0 and torch.isfinite(agent.bucket.flat_param).all()
