@@ -1,0 +1,44 @@
+"""Stress: K7 (both builds) and the chained minibatch on random shapes -- tiny and ragged minibatches, every head width,
+odd observation widths -- checked against the per-op autograd path.  Looks for hangs (run it under `timeout`) and
+for shape-dependent errors the parametrised tests do not reach."""
+import os, sys, random
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from tests.test_mlp_fused import _setup
+random.seed(int(os.environ.get("FUZZ_SEED", "1")))
+n_cases = int(os.environ.get("FUZZ_CASES", "120"))
+worst = 0.0
+for case in range(n_cases):
+    cont = random.random() < 0.6
+    D = random.choice([2, 4, 6, 8, 10, 16, 30, 32, 48, 62, 64])
+    A = random.randint(1, 16) if cont else random.randint(2, 16)
+    T, N = random.choice([(4, 32), (8, 64), (16, 64), (32, 128)])
+    B = T * N
+    M = random.choice([1, 2, 31, 32, 33, 63, 64, 65, 100, 255, 256, 257, 1000, B // 4, B // 2, B])
+    M = max(1, min(M, B))
+    os.environ["AURPPO_MLP_VARIANT"] = random.choice(["1", "2", "2", "2"])
+    H, pol, bucket, obs, act, rec = _setup(T, N, D, A, seed=case, cont=cont)
+    lay = H.mlp_layout(pol, bucket)
+    idx = torch.randperm(B, device="cuda")[:M].int()
+    norm_adv = random.random() < 0.7 and M > 1
+    vmode = random.choice([0, 1, 2])
+    mb = H.gather(idx, [obs, act, rec])
+    _, nlp, ent, nv = pol.evaluate(mb[0], mb[1])
+    sc_ref = torch.empty(9, device="cuda")
+    loss = H.ppo_loss_packed(nlp, nv, ent, mb[2], 0.2, 0.01, 0.5, norm_adv, vmode, sc_ref)
+    bucket.zero_grad()
+    loss.backward()
+    g_ref = bucket.flat_grad[:lay["n_params"]].clone()
+    g_out = torch.full_like(bucket.flat_grad, float("nan"))
+    sc = H.mlp_ppo_step(obs, act, rec, idx, bucket.flat_param, lay, g_out, 0.2, 0.01, 0.5, norm_adv, vmode)
+    torch.cuda.synchronize()
+    g = g_out[:lay["n_params"]]
+    assert torch.isfinite(g).all(), (case, "non-finite gradient")
+    scale = float(g_ref.abs().max()) + 1e-12
+    err = float((g - g_ref).abs().max()) / scale
+    worst = max(worst, err)
+    assert err < 1e-4, (case, cont, D, A, M, norm_adv, vmode, err)
+    assert torch.allclose(sc, sc_ref, rtol=5e-5, atol=5e-6, equal_nan=True), (case, sc, sc_ref)
+    if case % 20 == 0:
+        print(f"case {case}: ok (cont={cont} D={D} A={A} B={B} M={M}), worst relative gradient error so far {worst:.2e}", flush=True)
+print(f"{n_cases} cases ok, worst relative gradient error {worst:.2e}")
