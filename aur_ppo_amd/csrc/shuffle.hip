@@ -98,10 +98,10 @@ constexpr int kRingMirror = 64;
 //
 // The recurrence is x[m] = x[m-227] ^ mix(x[m-624], x[m-623]).  Taken 227 words at a time ("phase"), with thread
 // t owning offset t of EVERY phase, the x[m-227] term is the thread's own previous output -- a register.  The two
-// other inputs were written at least two phases earlier, so they are read from a small circular window in LDS one
-// phase ahead of their use.  What is left on the critical path of a phase is one XOR, one LDS write and one
-// barrier; tempering and the (coalesced) ring store hang off the side.  The block formulation this replaces needed
-// three barrier-separated passes with an LDS round trip each per 624 words.
+// other inputs were written at least two phases earlier, so they come from a small circular window in LDS.  What is
+// left on the critical path of a phase is one XOR, one LDS write and the barrier that publishes it -- and two phases
+// share one barrier (below); tempering and the (coalesced) ring store hang off the side.  The block formulation
+// this replaces needed three barrier-separated passes with an LDS round trip each per 624 words.
 constexpr int kFillWin = 2048;   // LDS window over the untempered stream (power of two, >= 624 + 2 * 227)
 
 __global__ __launch_bounds__(kFillThreads) void k_mt_fill(uint32_t* __restrict__ last, uint32_t* __restrict__ ring,
@@ -126,29 +126,38 @@ __global__ __launch_bounds__(kFillThreads) void k_mt_fill(uint32_t* __restrict__
     const bool lane_on = tid < kMtD;
     int m = kMtN + tid;                                         // my word of phase 0
     uint32_t prev = lane_on ? win[kMtM + tid] : 0u;             // x[m - 227]
-    uint32_t a = win[tid & (kFillWin - 1)], b = win[(tid + 1) & (kFillWin - 1)];   // x[m - 624], x[m - 623]
     long long at = S % ring_cap + tid;                          // ring slot of x[m]
     if (at >= ring_cap) at -= ring_cap;
+    // Two phases per barrier.  Phase p reads words written in phases p-3 and p-2, so the two phases of a pair (2g, 2g+1)
+    // only need what was complete at the barrier that ended pair g-1 -- a barrier costs about as much as the rest of a
+    // phase (rocprof: ~420 cycles per phase whatever the arithmetic in it), so pairing halves what dominates.  Three
+    // in a row would need phase 3g's words inside the same group.
     const int nphase = (total + kMtD - 1) / kMtD;
-    for (int p = 0; p < nphase; ++p) {
-        const bool on = lane_on && m < m_end;
-        // next phase's inputs first, so that their LDS latency runs under this phase's arithmetic: x[m + 227 - 624]
-        // and its successor were written in phase p-1 at the latest (the barrier below orders phase p-1 before us)
-        const uint32_t an = win[(m - kMtM) & (kFillWin - 1)];
-        const uint32_t bn = win[(m - kMtM + 1) & (kFillWin - 1)];
-        const uint32_t nw = prev ^ mt_mix(a, b);
-        if (on) win[m & (kFillWin - 1)] = nw;
-        prev = nw;
-        if (on) {
-            const uint32_t t = mt_temper(nw);
+    for (int p = 0; p < nphase; p += 2) {
+        // inputs of both phases, all written before the last barrier: x[m-624], x[m-623] and the same 227 further on
+        const uint32_t a0 = win[(m - kMtN) & (kFillWin - 1)], b0 = win[(m - kMtN + 1) & (kFillWin - 1)];
+        const uint32_t a1 = win[(m - kMtM) & (kFillWin - 1)], b1 = win[(m - kMtM + 1) & (kFillWin - 1)];
+        const uint32_t n0 = prev ^ mt_mix(a0, b0);          // x[m]       = x[m - 227] ^ ...
+        const uint32_t n1 = n0 ^ mt_mix(a1, b1);            // x[m + 227] = x[m]       ^ ...
+        prev = n1;
+        const bool on0 = lane_on && m < m_end, on1 = lane_on && m + kMtD < m_end;
+        if (on0) {
+            win[m & (kFillWin - 1)] = n0;
+            const uint32_t t = mt_temper(n0);
             ring[at] = t;
             if (at < kRingMirror) ring[ring_cap + at] = t;
         }
-        m += kMtD;
-        at += kMtD;
+        long long at1 = at + kMtD;
+        if (at1 >= ring_cap) at1 -= ring_cap;
+        if (on1) {
+            win[(m + kMtD) & (kFillWin - 1)] = n1;
+            const uint32_t t = mt_temper(n1);
+            ring[at1] = t;
+            if (at1 < kRingMirror) ring[ring_cap + at1] = t;
+        }
+        m += 2 * kMtD;
+        at = at1 + kMtD;
         if (at >= ring_cap) at -= ring_cap;
-        a = an;
-        b = bn;
         __syncthreads();
     }
     for (int k = tid; k < kMtN; k += kFillThreads) last[k] = win[(m_end - kMtN + k) & (kFillWin - 1)];
