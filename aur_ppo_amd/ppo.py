@@ -250,8 +250,12 @@ class ppo:
         if self._mlp is not None and hasattr(self.ops, "mlp_act"):
             # K8: forward of both nets, sampling, log-prob and the three buffer row stores in one launch
             cont = self._mlp["continuous"]
-            noise = (torch.randn((self.num_envs, self._mlp["A"]), device=self.device) if cont
-                     else torch.rand(self.num_envs, device=self.device))
+            pre = getattr(self, "_rollout_noise", None)      # train() draws the whole rollout's noise in one call
+            if pre is not None and step < pre.shape[0]:
+                noise = pre[step]
+            else:
+                noise = (torch.randn((self.num_envs, self._mlp["A"]), device=self.device) if cont
+                         else torch.rand(self.num_envs, device=self.device))
             action, _, _ = self.ops.mlp_act(next_obs.to(self.device).contiguous(), noise, self.bucket.flat_param, self._mlp,
                                             self.buffer.actions[step], self.buffer.log_probs[step], self.buffer.values[step])
             if not cont:
@@ -483,6 +487,10 @@ class ppo:
                 self.set_lr(frac * self.learning_rate)
             if self._perms is None:
                 self._prefetch_perms()              # overlaps the rollout below
+            if self._mlp is not None and hasattr(self.ops, "mlp_act"):
+                # one generator call per rollout instead of one per step (the sampling noise K8 consumes)
+                self._rollout_noise = (torch.randn((self.num_steps, self.num_envs, self._mlp["A"]), device=self.device)
+                                       if self._mlp["continuous"] else torch.rand((self.num_steps, self.num_envs), device=self.device))
             for step in range(0, self.num_steps):
                 global_step += 1 * self.num_envs * self.world
                 self.buffer.states[step] = next_obs
