@@ -26,6 +26,7 @@ class _Space:
 
 class SyntheticVecEnv:
     device_native = True
+    capturable = True          # step() is a fixed sequence of device ops: a whole rollout can be captured as one hipGraph
 
     def __init__(self, num_envs, obs_dim, act_dim, continuous, device, seed=1234, p_done=0.02):
         self.num_envs = num_envs
@@ -47,6 +48,10 @@ class SyntheticVecEnv:
         rew = torch.randn(self.num_envs, device=self.device, generator=self.gen)
         done = (torch.rand(self.num_envs, device=self.device, generator=self.gen) < self.p_done).float()
         return self._obs(), rew, done, None, {}
+
+    def generators(self):
+        """Generators step() draws from (a graph capture has to know them)."""
+        return [self.gen]
 
     def close(self):
         pass

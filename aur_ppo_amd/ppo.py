@@ -142,6 +142,7 @@ class ppo:
             self._mlp = ops.mlp_layout(self.policy, self.bucket)
         # the flat bucket holds the MLP policy and nothing else (up to alignment padding): K7 + clip + Adam can chain
         self._bucket_is_policy = self._mlp is not None and self.bucket.numel == self._mlp["n_params"]
+        self._ro_state, self._ro_graph, self._ro_obs, self._ro_done, self._ro_out = 0, None, None, None, None   # captured rollout
         self._graph = None         # captured update (hipGraph), see update()
         self._graph_state = 0      # 0: next update runs eagerly (warm-up), 1: capture, 2: replay
         self._perm_static = None
@@ -284,6 +285,46 @@ class ppo:
                     self.x_indices.append(global_step)
                     break
         return next_obs, next_done
+
+    def _rollout_steps(self, next_obs, next_done, global_step, writer):
+        """The T rollout steps of src/ppo.py:201-205."""
+        if self._mlp is not None and hasattr(self.ops, "mlp_act"):
+            # one generator call per rollout instead of one per step (the sampling noise K8 consumes)
+            self._rollout_noise = (torch.randn((self.num_steps, self.num_envs, self._mlp["A"]), device=self.device)
+                                   if self._mlp["continuous"] else torch.rand((self.num_steps, self.num_envs), device=self.device))
+        for step in range(0, self.num_steps):
+            global_step += 1 * self.num_envs * self.world
+            self.buffer.states[step] = next_obs
+            self.buffer.terminals[step] = next_done
+            next_obs, next_done = self.rewards_to_go(step, next_obs, global_step, writer)
+        return next_obs, next_done, global_step
+
+    def _rollout(self, next_obs, next_done, global_step, writer):
+        """One rollout.  With a device-resident env whose step() is a fixed sequence of device ops (``capturable``), the MLP
+        policy (K8) and one process, the T steps -- ~10 launches each, host-bound -- are captured once as a hipGraph and
+        replayed: rollout 1 runs eagerly, rollout 2 is captured, later ones replay."""
+        env = self.envs
+        ok = (self.use_graph and self.world == 1 and self._mlp is not None and hasattr(self.ops, "mlp_act")
+              and getattr(env, "device_native", False) and getattr(env, "capturable", False) and self.device.type == "cuda")
+        if not ok or self._ro_state == 0:
+            self._ro_state = 1 if ok else 0
+            return self._rollout_steps(next_obs, next_done, global_step, writer)
+        if self._ro_obs is None:
+            self._ro_obs, self._ro_done = torch.empty_like(next_obs), torch.empty_like(next_done)
+        self._ro_obs.copy_(next_obs)
+        self._ro_done.copy_(next_done)
+        if self._ro_state == 1:
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            for gen in env.generators():
+                g.register_generator_state(gen)
+            with torch.cuda.graph(g):
+                o, d, _ = self._rollout_steps(self._ro_obs, self._ro_done, 0, None)
+                self._ro_out = (o, d)
+            self._ro_graph = g
+            self._ro_state = 2
+        self._ro_graph.replay()
+        return self._ro_out[0], self._ro_out[1], global_step + self.num_steps * self.num_envs * self.world
 
     # ------------------------------------------------------------------ advantages (src/ppo.py:125-166)
     def _gae(self, next_value, next_done, mode):
@@ -487,15 +528,7 @@ class ppo:
                 self.set_lr(frac * self.learning_rate)
             if self._perms is None:
                 self._prefetch_perms()              # overlaps the rollout below
-            if self._mlp is not None and hasattr(self.ops, "mlp_act"):
-                # one generator call per rollout instead of one per step (the sampling noise K8 consumes)
-                self._rollout_noise = (torch.randn((self.num_steps, self.num_envs, self._mlp["A"]), device=self.device)
-                                       if self._mlp["continuous"] else torch.rand((self.num_steps, self.num_envs), device=self.device))
-            for step in range(0, self.num_steps):
-                global_step += 1 * self.num_envs * self.world
-                self.buffer.states[step] = next_obs
-                self.buffer.terminals[step] = next_done
-                next_obs, next_done = self.rewards_to_go(step, next_obs, global_step, writer)
+            next_obs, next_done, global_step = self._rollout(next_obs, next_done, global_step, writer)
             returns, advantages = self.advantages(next_obs, next_done)
             n_steps = self.update(returns, advantages)
             self._log_update(writer, returns, n_steps, global_step, start_time)

@@ -200,3 +200,26 @@ def test_single_process_update_takes_the_chained_entry_point(monkeypatch):
     torch.cuda.synchronize()
     assert n == 12 and calls == {"minibatch": 12, "step": 0, "clip_adam": 0}
     assert float(agent._adam_t) == 12.0 and torch.isfinite(agent.bucket.flat_param).all()
+
+
+def test_captured_rollout_matches_eager_rollout():
+    """train() on the device-resident synthetic env: rollouts replayed from a hipGraph (capturable env + K8) leave the
+    same policy as rollouts run step by step -- same generators, same draws, same buffer contents."""
+    def run(graph):
+        hp = dict(gym_id="Synthetic-v0", seed=1.0, num_steps=8, gae=True, total_timesteps=8 * 64 * 5, anneal_lr=True,
+                  gae_lambda=0.95, num_update_epochs=2, num_envs=64, num_minibatches=2, entropy_coeff=0.0, value_coeff=0.5,
+                  clip_coeff=0.2, clip_vloss=True, max_grad_norm=0.5, target_kl=None, norm_adv=True, capture_video=False,
+                  hidden_dim=64, continuous=True, learning_rate=3e-4, exp_name="t", num_layers=2, dropout=0.0, gamma=0.99,
+                  track=False, log=False, save=False, obs_dim=16, act_dim=3, hip_graph=graph)
+        torch.manual_seed(7)
+        agent = _agent(hp)
+        agent.train()
+        torch.cuda.synchronize()
+        return agent, agent.bucket.flat_param.clone(), agent.buffer.states.clone(), agent.buffer.actions.clone()
+
+    a_g, p_g, s_g, act_g = run(True)
+    a_e, p_e, s_e, act_e = run(False)
+    assert a_g._ro_state == 2 and a_g._ro_graph is not None and a_e._ro_graph is None
+    assert torch.equal(s_g, s_e)                       # the env's generator advanced identically
+    torch.testing.assert_close(act_g, act_e, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(p_g, p_e, rtol=1e-4, atol=1e-6)
