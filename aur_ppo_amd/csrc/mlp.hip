@@ -789,7 +789,7 @@ static int mlp_step_impl(const float* obs, const float* actions, const float* re
     AURPPO_REQUIRE(obs && actions && rec && idx && params && layout_h && grads && out_scalars && workspace, AURPPO_EINVAL,
                    "aurppo_mlp_ppo_step_f32: null pointer");
     AURPPO_REQUIRE(hidden == H, AURPPO_ESHAPE, "aurppo_mlp_ppo_step_f32: hidden_dim=%d (only %d is built)", hidden, H);
-    AURPPO_REQUIRE(D >= 2 && D <= H && D % 2 == 0, AURPPO_ESHAPE, "aurppo_mlp_ppo_step_f32: state_dim=%d must be even, 2..%d", D, H);
+    AURPPO_REQUIRE(D >= 1 && D <= H, AURPPO_ESHAPE, "aurppo_mlp_ppo_step_f32: state_dim=%d must be 1..%d", D, H);
     AURPPO_REQUIRE(A >= 1 && A <= AP && (continuous || A >= 2), AURPPO_ESHAPE,
                    "aurppo_mlp_ppo_step_f32: action_dim=%d must be 1..%d (>= 2 logits for a Categorical head)", A, AP);
     AURPPO_REQUIRE(M > 0 && n_params > 0, AURPPO_ESHAPE, "aurppo_mlp_ppo_step_f32: M=%d n_params=%d", M, n_params);
@@ -941,7 +941,7 @@ extern "C" int aurppo_mlp_ppo_apply_f32(float* params, float* grads, float* exp_
                                         const float* rec, const int32_t* next_idx, int next_M, void* workspace, void* stream) {
     AURPPO_REQUIRE(params && grads && exp_avg && exp_avg_sq && layout_h && lr_dev && step_dev && out_norm && workspace,
                    AURPPO_EINVAL, "aurppo_mlp_ppo_apply_f32: null pointer");
-    AURPPO_REQUIRE(n_params > 0 && D >= 2 && D <= H && D % 2 == 0, AURPPO_ESHAPE, "aurppo_mlp_ppo_apply_f32: n_params=%d D=%d",
+    AURPPO_REQUIRE(n_params > 0 && D >= 1 && D <= H, AURPPO_ESHAPE, "aurppo_mlp_ppo_apply_f32: n_params=%d D=%d",
                    n_params, D);
     AURPPO_REQUIRE(!next_idx || (next_M > 0 && rec), AURPPO_ESHAPE, "aurppo_mlp_ppo_apply_f32: next_M=%d", next_M);
     AURPPO_REQUIRE(aligned_to(workspace, 16) && (!rec || aligned_to(rec, 16)), AURPPO_EINVAL,
@@ -970,7 +970,7 @@ extern "C" int aurppo_mlp_act_f32(const float* obs, const float* noise, int N, i
     AURPPO_REQUIRE(obs && params && layout_h && value, AURPPO_EINVAL, "aurppo_mlp_act_f32: null pointer");
     AURPPO_REQUIRE(!noise || (actions && logp), AURPPO_EINVAL, "aurppo_mlp_act_f32: sampling needs actions and logp outputs");
     AURPPO_REQUIRE(hidden == H, AURPPO_ESHAPE, "aurppo_mlp_act_f32: hidden_dim=%d (only %d is built)", hidden, H);
-    AURPPO_REQUIRE(D >= 2 && D <= H && D % 2 == 0, AURPPO_ESHAPE, "aurppo_mlp_act_f32: state_dim=%d must be even, 2..%d", D, H);
+    AURPPO_REQUIRE(D >= 1 && D <= H, AURPPO_ESHAPE, "aurppo_mlp_act_f32: state_dim=%d must be 1..%d", D, H);
     AURPPO_REQUIRE(A >= 1 && A <= AP && (continuous || A >= 2), AURPPO_ESHAPE, "aurppo_mlp_act_f32: action_dim=%d", A);
     AURPPO_REQUIRE(N > 0 && n_params > 0, AURPPO_ESHAPE, "aurppo_mlp_act_f32: N=%d n_params=%d", N, n_params);
     ActArgs a;

@@ -296,7 +296,7 @@ def mlp_layout(policy, bucket):
         return None
     D = policy.actor.net[0].weight.shape[1]
     A = policy.actor.net[4].weight.shape[0]
-    if D % 2 or D > MLP_MAX_D or A > MLP_MAX_A or policy.critic.net[4].weight.shape[0] != 1 or (not cont and A < 2):
+    if D > MLP_MAX_D or A > MLP_MAX_A or policy.critic.net[4].weight.shape[0] != 1 or (not cont and A < 2):
         return None
     return dict(offsets=seq, n_params=pos, D=D, A=A, continuous=cont)
 

@@ -39,7 +39,8 @@ def variant(request, monkeypatch):
 
 
 @pytest.mark.parametrize("T,N,D,A,M", [(8, 64, 64, 6, 256), (16, 64, 64, 6, 1000), (4, 32, 4, 1, 77), (8, 32, 32, 16, 128),
-                                         (8, 32, 6, 3, 100), (8, 64, 10, 9, 31), (128, 1024, 64, 6, 131072)])
+                                         (8, 32, 6, 3, 100), (8, 64, 10, 9, 31), (8, 32, 3, 1, 100), (8, 64, 11, 3, 333),
+                                         (16, 64, 17, 6, 1000), (128, 1024, 64, 6, 131072)])
 @pytest.mark.parametrize("norm_adv,vmode", [(True, 1), (False, 2), (True, 0)])
 def test_fused_step_matches_autograd_path(T, N, D, A, M, norm_adv, vmode, variant):
     H, pol, bucket, obs, act, rec = _setup(T, N, D, A)
@@ -89,7 +90,8 @@ def test_fused_step_rejects_unsupported_shapes():
     assert H.mlp_layout(wide, FlatBucket(wide.parameters())) is None
 
 
-@pytest.mark.parametrize("T,N,D,A,M", [(8, 64, 4, 2, 200), (16, 64, 64, 16, 1024), (8, 64, 6, 11, 333), (128, 256, 8, 5, 32768)])
+@pytest.mark.parametrize("T,N,D,A,M", [(8, 64, 4, 2, 200), (16, 64, 64, 16, 1024), (8, 64, 6, 11, 333), (8, 64, 5, 3, 200),
+                                         (128, 256, 8, 5, 32768)])
 @pytest.mark.parametrize("norm_adv,vmode,ec", [(True, 1, 0.01), (False, 2, 0.05)])
 def test_fused_step_categorical_head_matches_autograd_path(T, N, D, A, M, norm_adv, vmode, ec, variant):
     """Discrete policy (CartPole-style, BASELINE configs[0]): Categorical log-prob / entropy and their gradients."""
@@ -121,7 +123,8 @@ def test_fused_step_categorical_head_matches_autograd_path(T, N, D, A, M, norm_a
 
 
 # ---------------------------------------------------------------------------------- K8: rollout step
-@pytest.mark.parametrize("N,D,A,cont", [(4096, 64, 6, True), (77, 4, 2, False), (256, 16, 16, True), (33, 8, 5, False), (1, 64, 1, True)])
+@pytest.mark.parametrize("N,D,A,cont", [(4096, 64, 6, True), (77, 4, 2, False), (256, 16, 16, True), (33, 8, 5, False), (1, 64, 1, True),
+                                        (100, 11, 3, True), (64, 3, 4, False)])
 def test_act_kernel_matches_torch_formulas(N, D, A, cont):
     H, pol, bucket, _obs, _act, _rec = _setup(2, 32, D, A, seed=2, cont=cont)
     lay = H.mlp_layout(pol, bucket)

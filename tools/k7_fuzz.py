@@ -10,7 +10,7 @@ n_cases = int(os.environ.get("FUZZ_CASES", "120"))
 worst = 0.0
 for case in range(n_cases):
     cont = random.random() < 0.6
-    D = random.choice([2, 4, 6, 8, 10, 16, 30, 32, 48, 62, 64])
+    D = random.choice([1, 2, 3, 4, 5, 6, 8, 10, 11, 16, 17, 30, 32, 33, 48, 62, 63, 64])
     A = random.randint(1, 16) if cont else random.randint(2, 16)
     T, N = random.choice([(4, 32), (8, 64), (16, 64), (32, 128)])
     B = T * N
