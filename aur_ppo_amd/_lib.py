@@ -14,7 +14,7 @@ SYMBOLS = (
     "aurppo_mt19937_set_state", "aurppo_arange_i32", "aurppo_shuffle_i32", "aurppo_shuffle_epochs_i32",
     "aurppo_gather_f32", "aurppo_loss_workspace_bytes", "aurppo_loss_fwd_bwd_f32", "aurppo_loss_fwd_bwd_packed_f32",
     "aurppo_clip_workspace_bytes", "aurppo_grad_norm_clip_f32", "aurppo_mlp_workspace_bytes", "aurppo_mlp_ppo_step_f32",
-    "aurppo_mlp_ppo_step_ev_f32", "aurppo_mlp_ppo_minibatch_f32", "aurppo_mlp_ppo_grad_f32", "aurppo_mlp_ppo_apply_f32", "aurppo_mlp_act_f32", "aurppo_clip_adam_f32",
+    "aurppo_mlp_ppo_step_ev_f32", "aurppo_mlp_ppo_minibatch_f32", "aurppo_mlp_ppo_grad_f32", "aurppo_mlp_ppo_apply_f32", "aurppo_pack_records_f32", "aurppo_mlp_act_f32", "aurppo_clip_adam_f32",
 )
 
 _lib = None
@@ -64,7 +64,8 @@ def load() -> C.CDLL:
     lib.aurppo_mlp_ppo_step_f32.argtypes = [vp] * 4 + [i32] * 5 + [vp, C.POINTER(i32), i32, vp, f64, f64, f64, i32, i32, vp, vp, vp]
     lib.aurppo_mlp_ppo_step_ev_f32.argtypes = lib.aurppo_mlp_ppo_step_f32.argtypes + [vp, vp]
     lib.aurppo_mlp_ppo_grad_f32.argtypes = [vp] * 4 + [i32] * 5 + [vp, C.POINTER(i32), i32, vp, f64, f64, f64, i32, i32, vp, vp, i32, vp, vp]
-    lib.aurppo_mlp_ppo_apply_f32.argtypes = [vp] * 4 + [C.POINTER(i32), i32, i32, f64, f64, vp, vp, f64, f64, f64, vp, vp, vp, i32, vp, vp]
+    lib.aurppo_mlp_ppo_apply_f32.argtypes = [vp] * 4 + [C.POINTER(i32), i32, i32, f64, f64, vp, vp, f64, f64, f64, vp, vp, i32, vp, i32, vp, vp]
+    lib.aurppo_pack_records_f32.argtypes = [vp, vp, i32, i32, vp, vp]
     lib.aurppo_mlp_ppo_minibatch_f32.argtypes = ([vp] * 4 + [i32] * 5 + [vp, C.POINTER(i32), i32, vp, f64, f64, f64, i32, i32, vp] +
                                                  [vp, vp, f64, vp, vp, f64, f64, f64, vp, vp, i32, i32, vp, vp])
     lib.aurppo_clip_workspace_bytes.argtypes = [C.c_int64]

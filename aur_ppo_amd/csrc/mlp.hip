@@ -46,7 +46,8 @@ namespace {
 // Also lays out W1 of both nets in the B-operand order of k_mlp_step2's layer-1 MFMA chain (w1op != nullptr):
 // w1op[(w * 32 + m) * 64 + lane] = W1[net = w >> 1][(w & 1) * 32 + (lane & 31)][2m + (lane >> 5)], zero beyond D, so
 // that wave w reads its slice with 32 fully coalesced loads per tile instead of holding it in registers.
-__global__ __launch_bounds__(256) void k_adv_stats_idx(const float4* __restrict__ rec, const int32_t* __restrict__ idx,
+__global__ __launch_bounds__(256) void k_adv_stats_idx(const float4* __restrict__ rec, int rec_stride,
+                                                       const int32_t* __restrict__ idx,
                                                        int M, double (*__restrict__ stats)[2], const float* __restrict__ params,
                                                        int w1_actor, int w1_critic, int D, float* __restrict__ w1op,
                                                        unsigned* __restrict__ tile_counter) {
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256) void k_adv_stats_idx(const float4* __restrict_
     }
     double s = 0.0, q = 0.0;
     for (int i = blockIdx.x * kThreads + threadIdx.x; i < M; i += gridDim.x * kThreads) {
-        const double a = (double)rec[idx[i]].y;
+        const double a = (double)rec[(size_t)idx[i] * rec_stride].y;
         s += a;
         q += a * a;
     }
@@ -190,6 +191,9 @@ __global__ __launch_bounds__(256, 1) void k_mlp_step(const MlpArgs a) {
         const int m = tile * R + tid;
         return (tile < n_tiles && m < a.h.M) ? a.idx[m] : -1;
     };
+    // packed records (actions == nullptr): a sample's action row sits behind its 16-B record in one 64-B line
+    const float* const act_base = a.actions ? a.actions : reinterpret_cast<const float*>(a.rec) + 4;
+    const int act_stride = a.actions ? AW : 16;
     auto prefetch = [&](const int* sidx) {
 #pragma unroll
         for (int u = 0; u < XPT; ++u) {
@@ -199,11 +203,11 @@ __global__ __launch_bounds__(256, 1) void k_mlp_step(const MlpArgs a) {
 #pragma unroll
         for (int u = 0; u < APT; ++u) {
             const int src = a_row[u] >= 0 ? sidx[a_row[u]] : -1;
-            ar[u] = src >= 0 ? a.actions[(size_t)src * AW + a_col[u]] : 0.0f;
+            ar[u] = src >= 0 ? act_base[(size_t)src * act_stride + a_col[u]] : 0.0f;
         }
         if (tid < R) {
             p_src = sidx[tid];
-            if (p_src >= 0) p_rec = a.rec[p_src];
+            if (p_src >= 0) p_rec = a.rec[(size_t)p_src * a.rec_stride];
         }
     };
     const int stride = gridDim.x;
@@ -677,8 +681,9 @@ __global__ __launch_bounds__(kThreads) void k_adam_chain(float* __restrict__ p, 
                                                          const float* __restrict__ step, double beta1, double beta2,
                                                          double eps, float* __restrict__ out_norm, float gscale, int nb_upd,
                                                          int w1_actor, int w1_critic, int D, float* __restrict__ w1op,
-                                                         const float4* __restrict__ rec, const int32_t* __restrict__ next_idx,
-                                                         int next_M, double (*__restrict__ stats)[2]) {
+                                                         const float4* __restrict__ rec, int rec_stride,
+                                                         const int32_t* __restrict__ next_idx, int next_M,
+                                                         double (*__restrict__ stats)[2]) {
     __shared__ double sc[2][kThreads / kWave];
     __shared__ float s_coef;
     if ((int)blockIdx.x < nb_upd) {
@@ -712,7 +717,7 @@ __global__ __launch_bounds__(kThreads) void k_adam_chain(float* __restrict__ p, 
         const int nsb = gridDim.x - nb_upd, b = blockIdx.x - nb_upd;
         double s = 0.0, q = 0.0;
         for (int i = b * kThreads + threadIdx.x; i < next_M; i += nsb * kThreads) {
-            const double x = (double)rec[next_idx[i]].y;
+            const double x = (double)rec[(size_t)next_idx[i] * rec_stride].y;
             s += x;
             q += x * x;
         }
@@ -786,8 +791,11 @@ static int mlp_step_impl(const float* obs, const float* actions, const float* re
                          int A, int continuous, int hidden, const float* params, const int* layout_h, int n_params, float* grads,
                          double clip, double ent_coef, double vf_coef, int norm_adv, int vloss_mode, float* out_scalars,
                          void* workspace, void* stream, void* ev_begin, void* ev_end, const ChainArgs* chain = nullptr) {
-    AURPPO_REQUIRE(obs && actions && rec && idx && params && layout_h && grads && out_scalars && workspace, AURPPO_EINVAL,
+    AURPPO_REQUIRE(obs && rec && idx && params && layout_h && grads && out_scalars && workspace, AURPPO_EINVAL,
                    "aurppo_mlp_ppo_step_f32: null pointer");
+    // actions == NULL: packed records -- rec is (B, 16), floats 4.. of a record hold the sample's action row
+    AURPPO_REQUIRE(actions || (continuous ? A : 1) <= 12, AURPPO_ESHAPE,
+                   "aurppo_mlp_ppo_step_f32: packed records hold at most 12 action floats (action_dim=%d)", A);
     AURPPO_REQUIRE(hidden == H, AURPPO_ESHAPE, "aurppo_mlp_ppo_step_f32: hidden_dim=%d (only %d is built)", hidden, H);
     AURPPO_REQUIRE(D >= 1 && D <= H, AURPPO_ESHAPE, "aurppo_mlp_ppo_step_f32: state_dim=%d must be 1..%d", D, H);
     AURPPO_REQUIRE(A >= 1 && A <= AP && (continuous || A >= 2), AURPPO_ESHAPE,
@@ -798,6 +806,7 @@ static int mlp_step_impl(const float* obs, const float* actions, const float* re
                    "aurppo_mlp_ppo_step_f32: workspace / rec not 16-byte aligned");
     MlpArgs a;
     a.obs = obs; a.actions = actions; a.rec = reinterpret_cast<const float4*>(rec); a.idx = idx; a.params = params;
+    a.rec_stride = actions ? 1 : 4;
     a.D = D; a.A = A;
     a.continuous = continuous ? 1 : 0;
     // layout_h: w1a,b1a,w2a,b2a,w3a,b3a, w1c,b1c,w2c,b2c,w3c,b3c, logstd
@@ -825,7 +834,7 @@ static int mlp_step_impl(const float* obs, const float* actions, const float* re
     a.tile_counter = wv.tile_counter;
     double* sq_part = wv.sq_part;
     if (!(chain && chain->chained)) {   // otherwise the previous chained call has prepared all of this
-        hipLaunchKernelGGL(k_adv_stats_idx, dim3(sb), dim3(kThreads), 0, s, a.rec, idx, M,
+        hipLaunchKernelGGL(k_adv_stats_idx, dim3(sb), dim3(kThreads), 0, s, a.rec, a.rec_stride, idx, M,
                            reinterpret_cast<double (*)[2]>(stats), params, a.L.w1[0], a.L.w1[1], D,
                            (variant == 2 || chain) ? a.w1op : nullptr, a.tile_counter);
         AURPPO_LAUNCH_CHECK("k_adv_stats_idx");
@@ -882,7 +891,7 @@ static int mlp_step_impl(const float* obs, const float* actions, const float* re
         hipLaunchKernelGGL(k_adam_chain, dim3(nb_upd + nsb), dim3(kThreads), 0, s, chain->params_rw, grads, chain->exp_avg,
                            chain->exp_avg_sq, n_params, sq_part, n_red, (float)chain->max_norm, chain->lr_dev,
                            chain->step_dev, chain->beta1, chain->beta2, chain->eps, chain->out_norm, 1.0f, nb_upd, a.L.w1[0],
-                           a.L.w1[1], D, a.w1op, a.rec, chain->next_idx, chain->next_M,
+                           a.L.w1[1], D, a.w1op, a.rec, a.rec_stride, chain->next_idx, chain->next_M,
                            reinterpret_cast<double (*)[2]>(stats));
         AURPPO_LAUNCH_CHECK("k_adam_chain");
     }
@@ -938,12 +947,14 @@ extern "C" int aurppo_mlp_ppo_grad_f32(const float* obs, const float* actions, c
 extern "C" int aurppo_mlp_ppo_apply_f32(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const int* layout_h,
                                         int n_params, int D, double grad_scale, double max_norm, const float* lr_dev,
                                         const float* step_dev, double beta1, double beta2, double eps, float* out_norm,
-                                        const float* rec, const int32_t* next_idx, int next_M, void* workspace, void* stream) {
+                                        const float* rec, int rec_floats, const int32_t* next_idx, int next_M,
+                                        void* workspace, void* stream) {
     AURPPO_REQUIRE(params && grads && exp_avg && exp_avg_sq && layout_h && lr_dev && step_dev && out_norm && workspace,
                    AURPPO_EINVAL, "aurppo_mlp_ppo_apply_f32: null pointer");
     AURPPO_REQUIRE(n_params > 0 && D >= 1 && D <= H, AURPPO_ESHAPE, "aurppo_mlp_ppo_apply_f32: n_params=%d D=%d",
                    n_params, D);
-    AURPPO_REQUIRE(!next_idx || (next_M > 0 && rec), AURPPO_ESHAPE, "aurppo_mlp_ppo_apply_f32: next_M=%d", next_M);
+    AURPPO_REQUIRE(!next_idx || (next_M > 0 && rec && (rec_floats == 4 || rec_floats == 16)), AURPPO_ESHAPE,
+                   "aurppo_mlp_ppo_apply_f32: next_M=%d rec_floats=%d", next_M, rec_floats);
     AURPPO_REQUIRE(aligned_to(workspace, 16) && (!rec || aligned_to(rec, 16)), AURPPO_EINVAL,
                    "aurppo_mlp_ppo_apply_f32: workspace / rec not 16-byte aligned");
     for (int k = 0; k < 12; ++k)
@@ -958,9 +969,42 @@ extern "C" int aurppo_mlp_ppo_apply_f32(float* params, float* grads, float* exp_
     hipLaunchKernelGGL(k_adam_chain, dim3(nb_upd + nsb), dim3(kThreads), 0, (hipStream_t)stream, params, grads, exp_avg,
                        exp_avg_sq, n_params, (const double*)nullptr, 0, (float)max_norm, lr_dev, step_dev, beta1, beta2, eps,
                        out_norm, (float)grad_scale, nb_upd, layout_h[0], layout_h[6], D, w1op,
-                       reinterpret_cast<const float4*>(rec), next_idx, next_idx ? next_M : 0,
+                       reinterpret_cast<const float4*>(rec), rec_floats == 16 ? 4 : 1, next_idx, next_idx ? next_M : 0,
                        reinterpret_cast<double (*)[2]>(stats));
     AURPPO_LAUNCH_CHECK("k_adam_chain");
+    return AURPPO_OK;
+}
+
+namespace {
+// rec64[b] = {rec4[b], actions[b][0 .. AW), 0 ...}: one 64-B line per sample for K7's record + action fetch
+__global__ __launch_bounds__(256) void k_pack_rec64(const float4* __restrict__ rec4, const float* __restrict__ actions, int B,
+                                                    int AW, float4* __restrict__ rec64) {
+    const int i = blockIdx.x * 64 + (threadIdx.x >> 2), q = threadIdx.x & 3;   // 4 lanes per sample, one float4 each
+    if (i >= B) return;
+    float4 v;
+    if (q == 0) {
+        v = rec4[i];
+    } else {
+        const int k0 = 4 * (q - 1);
+        const float* ar = actions + (size_t)i * AW;
+        v.x = k0 + 0 < AW ? ar[k0 + 0] : 0.0f;
+        v.y = k0 + 1 < AW ? ar[k0 + 1] : 0.0f;
+        v.z = k0 + 2 < AW ? ar[k0 + 2] : 0.0f;
+        v.w = k0 + 3 < AW ? ar[k0 + 3] : 0.0f;
+    }
+    rec64[(size_t)i * 4 + q] = v;
+}
+}  // namespace
+
+extern "C" int aurppo_pack_records_f32(const float* rec4, const float* actions, int B, int action_floats, float* rec64,
+                                       void* stream) {
+    AURPPO_REQUIRE(rec4 && actions && rec64, AURPPO_EINVAL, "aurppo_pack_records_f32: null pointer");
+    AURPPO_REQUIRE(B > 0 && action_floats >= 1 && action_floats <= 12, AURPPO_ESHAPE,
+                   "aurppo_pack_records_f32: B=%d action_floats=%d (1..12)", B, action_floats);
+    AURPPO_REQUIRE(aligned_to(rec4, 16) && aligned_to(rec64, 16), AURPPO_EINVAL, "aurppo_pack_records_f32: records not 16-byte aligned");
+    hipLaunchKernelGGL(k_pack_rec64, dim3((B + 63) / 64), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(rec4),
+                       actions, B, action_floats, reinterpret_cast<float4*>(rec64));
+    AURPPO_LAUNCH_CHECK("k_pack_rec64");
     return AURPPO_OK;
 }
 

@@ -247,6 +247,9 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
 
     const float* __restrict__ w1p = a.w1op + (size_t)w * 32 * kWave;
     const bool vec4 = (D % 4 == 0) && ((reinterpret_cast<size_t>(a.obs) & 15) == 0);
+    // packed records (actions == nullptr): a sample's action row sits behind its 16-B record in one 64-B line
+    const float* const act_base = a.actions ? a.actions : reinterpret_cast<const float*>(a.rec) + 4;
+    const int act_stride = a.actions ? AW : 16;
     // loss-lane coordinates, also the action staging slots: row lr = st >> 3, action dims lj = st & 7 and lj + 8
     float xr[8];            // next tile's observation elements, in flight
     float ar[2], act_cur[2] = {0.0f, 0.0f};
@@ -280,12 +283,12 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 a_ok[u] = src >= 0 && lj + 8 * u < AW;
-                ar[u] = a.actions[a_ok[u] ? (size_t)src * AW + lj + 8 * u : (size_t)0];
+                ar[u] = act_base[a_ok[u] ? (size_t)src * act_stride + lj + 8 * u : (size_t)0];
             }
         }
         if (w == 0) {   // lanes >= R mirror lanes < R
             p_src = sidx[st & (R - 1)];
-            p_rec = a.rec[p_src >= 0 ? p_src : 0];
+            p_rec = a.rec[(size_t)(p_src >= 0 ? p_src : 0) * a.rec_stride];
         }
     };
     auto load_w1 = [&](float (&w1r)[32], int ln) {

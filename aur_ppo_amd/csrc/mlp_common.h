@@ -25,7 +25,8 @@ struct MlpLayout {  // float offsets into the flat parameter / gradient bucket
 struct MlpArgs {
     const float* obs;      // (B, D) rollout observations (flattened buffer)
     const float* actions;  // (B, A)
-    const float4* rec;     // (B, 4) {old_logp, adv, ret, old_v}
+    const float4* rec;     // (B, 4) {old_logp, adv, ret, old_v}; packed mode: (B, 16) with the action row in floats 4..15
+    int rec_stride;        // float4s per record: 1, or 4 in packed mode (actions == nullptr)
     const int32_t* idx;    // (M,) minibatch permutation slice
     const float* params;   // flat bucket
     float* slabs;          // (grid, n_params) per-workgroup gradient slabs

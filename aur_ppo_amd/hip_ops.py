@@ -310,6 +310,34 @@ def mlp_step_flops(layout, M):
     return 2 * (fwd + bwd) * M
 
 
+def pack_records(rec, actions, out=None):
+    """(B, 16) packed records {old_logp, A, R, V, action row, 0 ...} for the fused MLP step (pass them as ``rec`` with
+    ``actions=None``): a sample's record and action row then share one 64-B line."""
+    lib = _lib_or_raise()
+    B = rec.shape[0]
+    aw = actions.numel() // B
+    if rec.numel() != 4 * B or aw * B != actions.numel() or not 1 <= aw <= 12:
+        raise ValueError("pack_records: need (B, 4) records and at most 12 action floats per sample")
+    if out is None:
+        out = torch.empty((B, 16), dtype=torch.float32, device=rec.device)
+    _check(lib.aurppo_pack_records_f32(_ptr(rec), _ptr(actions), B, aw, _ptr(out), _stream()), "aurppo_pack_records_f32")
+    return out
+
+
+def _mlp_buffers_ok(obs, actions, rec, layout):
+    D, A = layout["D"], layout["A"]
+    aw = A if layout.get("continuous", True) else 1
+    if obs.shape[-1] != D:
+        return False
+    if actions is None:                       # packed records
+        return aw <= 12 and rec.numel() == obs.shape[0] * 16
+    return actions.numel() == obs.shape[0] * aw and rec.numel() == obs.shape[0] * 4
+
+
+def _optr(t, dtype=torch.float32):
+    return _ptr(t, dtype) if t is not None else None
+
+
 def mlp_ppo_step(obs, actions, rec, idx, flat_param, layout, flat_grad, clip, ent_coef, vf_coef, norm_adv=True,
                  vloss_mode=VLOSS_CLIPPED, out_scalars=None, events=None):
     """K7: gather + evaluate + loss + backward for one minibatch of the MLP actor-critic; overwrites
@@ -318,13 +346,13 @@ def mlp_ppo_step(obs, actions, rec, idx, flat_param, layout, flat_grad, clip, en
     lib = _lib_or_raise()
     M, D, A, n = idx.numel(), layout["D"], layout["A"], layout["n_params"]
     cont = layout.get("continuous", True)
-    if obs.shape[-1] != D or actions.numel() != obs.shape[0] * (A if cont else 1) or rec.numel() != obs.shape[0] * 4:
+    if not _mlp_buffers_ok(obs, actions, rec, layout):
         raise ValueError("mlp_ppo_step: buffer shapes do not match the policy")
     if out_scalars is None:
         out_scalars = torch.empty(N_SCALARS, dtype=torch.float32, device=obs.device)
     ws = _workspace("mlp", lib.aurppo_mlp_workspace_bytes(n), obs.device)
     lay = (C.c_int * 13)(*layout["offsets"])
-    args = (_ptr(obs), _ptr(actions), _ptr(rec), _ptr(idx, torch.int32), M, D, A, int(cont), MLP_HIDDEN, _ptr(flat_param), lay, n,
+    args = (_ptr(obs), _optr(actions), _ptr(rec), _ptr(idx, torch.int32), M, D, A, int(cont), MLP_HIDDEN, _ptr(flat_param), lay, n,
             _ptr(flat_grad), float(clip), float(ent_coef), float(vf_coef), int(bool(norm_adv)), int(vloss_mode),
             _ptr(out_scalars), C.c_void_p(ws.data_ptr()), _stream())
     if events is None:
@@ -346,7 +374,7 @@ def mlp_ppo_minibatch(obs, actions, rec, idx, flat_param, layout, flat_grad, cli
     lib = _lib_or_raise()
     M, D, A, n = idx.numel(), layout["D"], layout["A"], layout["n_params"]
     cont = layout.get("continuous", True)
-    if obs.shape[-1] != D or actions.numel() != obs.shape[0] * (A if cont else 1) or rec.numel() != obs.shape[0] * 4:
+    if not _mlp_buffers_ok(obs, actions, rec, layout):
         raise ValueError("mlp_ppo_minibatch: buffer shapes do not match the policy")
     if min(flat_param.numel(), flat_grad.numel(), exp_avg.numel(), exp_avg_sq.numel()) < n:
         raise ValueError("mlp_ppo_minibatch: the flat bucket is smaller than the policy")
@@ -354,7 +382,7 @@ def mlp_ppo_minibatch(obs, actions, rec, idx, flat_param, layout, flat_grad, cli
     ws = _workspace("mlp", lib.aurppo_mlp_workspace_bytes(n), obs.device)
     lay = (C.c_int * 13)(*layout["offsets"])
     _check(lib.aurppo_mlp_ppo_minibatch_f32(
-        _ptr(obs), _ptr(actions), _ptr(rec), _ptr(idx, torch.int32), M, D, A, int(cont), MLP_HIDDEN, _ptr(flat_param), lay, n,
+        _ptr(obs), _optr(actions), _ptr(rec), _ptr(idx, torch.int32), M, D, A, int(cont), MLP_HIDDEN, _ptr(flat_param), lay, n,
         _ptr(flat_grad), float(clip), float(ent_coef), float(vf_coef), int(bool(norm_adv)), int(vloss_mode), _ptr(out_scalars),
         _ptr(exp_avg), _ptr(exp_avg_sq), float(max_norm), _ptr(lr_dev), _ptr(step_dev), float(betas[0]), float(betas[1]),
         float(eps), _ptr(out_norm), _ptr(next_idx, torch.int32) if next_idx is not None else None,
@@ -370,12 +398,12 @@ def mlp_ppo_grad(obs, actions, rec, idx, flat_param, layout, flat_grad, clip, en
     lib = _lib_or_raise()
     M, D, A, n = idx.numel(), layout["D"], layout["A"], layout["n_params"]
     cont = layout.get("continuous", True)
-    if obs.shape[-1] != D or actions.numel() != obs.shape[0] * (A if cont else 1) or rec.numel() != obs.shape[0] * 4:
+    if not _mlp_buffers_ok(obs, actions, rec, layout):
         raise ValueError("mlp_ppo_grad: buffer shapes do not match the policy")
     ws = _workspace("mlp", lib.aurppo_mlp_workspace_bytes(n), obs.device)
     lay = (C.c_int * 13)(*layout["offsets"])
     _check(lib.aurppo_mlp_ppo_grad_f32(
-        _ptr(obs), _ptr(actions), _ptr(rec), _ptr(idx, torch.int32), M, D, A, int(cont), MLP_HIDDEN, _ptr(flat_param), lay, n,
+        _ptr(obs), _optr(actions), _ptr(rec), _ptr(idx, torch.int32), M, D, A, int(cont), MLP_HIDDEN, _ptr(flat_param), lay, n,
         _ptr(flat_grad), float(clip), float(ent_coef), float(vf_coef), int(bool(norm_adv)), int(vloss_mode), _ptr(out_scalars),
         _ptr(step_dev), int(bool(chained)), C.c_void_p(ws.data_ptr()), _stream()), "aurppo_mlp_ppo_grad_f32")
     return out_scalars
@@ -394,7 +422,8 @@ def mlp_ppo_apply(flat_param, flat_grad, exp_avg, exp_avg_sq, layout, lr_dev, st
     _check(lib.aurppo_mlp_ppo_apply_f32(
         _ptr(flat_param), _ptr(flat_grad), _ptr(exp_avg), _ptr(exp_avg_sq), lay, n, layout["D"], float(grad_scale), float(max_norm),
         _ptr(lr_dev), _ptr(step_dev), float(betas[0]), float(betas[1]), float(eps), _ptr(out_norm),
-        _ptr(rec) if rec is not None else None, _ptr(next_idx, torch.int32) if next_idx is not None else None,
+        _ptr(rec) if rec is not None else None, (rec.numel() // rec.shape[0]) if rec is not None else 4,
+        _ptr(next_idx, torch.int32) if next_idx is not None else None,
         int(next_idx.numel()) if next_idx is not None else 0, C.c_void_p(ws.data_ptr()), _stream()), "aurppo_mlp_ppo_apply_f32")
     return out_norm
 

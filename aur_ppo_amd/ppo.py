@@ -143,6 +143,7 @@ class ppo:
         # the flat bucket holds the MLP policy and nothing else (up to alignment padding): K7 + clip + Adam can chain
         self._bucket_is_policy = self._mlp is not None and self.bucket.numel == self._mlp["n_params"]
         self._ro_state, self._ro_graph, self._ro_obs, self._ro_done, self._ro_out = 0, None, None, None, None   # captured rollout
+        self._rec64 = None         # (B, 16) packed records for K7, rebuilt by _gae()
         self._graph = None         # captured update (hipGraph), see update()
         self._graph_state = 0      # 0: next update runs eagerly (warm-up), 1: capture, 2: replay
         self._perm_static = None
@@ -336,6 +337,11 @@ class ppo:
         ret, adv = self.ops.gae(b.rewards, b.values, b.terminals, next_value.contiguous(), next_done.contiguous(),
                                 self.gamma, self.gae_lambda, mode, log_probs=b.log_probs, rec=self._rec)
         self._rec_of = (ret, adv)
+        if self._mlp is not None and hasattr(self.ops, "pack_records"):
+            # K7 reads a sample's record and action row from one 64-B line (3 cache lines per sample instead of 4)
+            acts = b.actions.reshape(self.batch_size, -1)
+            if acts.shape[1] <= 12:
+                self._rec64 = self.ops.pack_records(self._rec, acts, out=self._rec64)
         return ret, adv
 
     def run_gae(self, next_value, next_done):
@@ -406,6 +412,7 @@ class ppo:
         # apply kernel), three launches + one collective per minibatch
         chain_dp = (packed and self._mlp is not None and self.world > 1 and self._fused_adam
                     and self._bucket_is_policy and hasattr(ops, "mlp_ppo_grad"))
+        k7_act, k7_rec = (None, self._rec64) if (packed and self._rec64 is not None) else (b_actions, self._rec)
         starts = list(range(0, B, M))
         for ep in range(self.num_update_epochs):
             idx_ep = perms[ep]
@@ -420,17 +427,17 @@ class ppo:
                         nxt = None
                     g = self.optimizer.param_groups[0]
                 if chain_dp:
-                    ops.mlp_ppo_grad(b_obs, b_actions, self._rec, mb_inds, self.bucket.flat_param, self._mlp,
+                    ops.mlp_ppo_grad(b_obs, k7_act, k7_rec, mb_inds, self.bucket.flat_param, self._mlp,
                                      self.bucket.flat_grad, self.clip_coeff, self.entropy_coeff, self.value_coeff,
                                      self.norm_adv, vmode, self._scalars[step], self._adam_t, chained=step > 0)
                     D.allreduce_sum_(self.bucket.flat_grad, self.world)
                     ops.mlp_ppo_apply(self.bucket.flat_param, self.bucket.flat_grad, self._adam_m, self._adam_v, self._mlp,
                                       self._lr_tensor, self._adam_t, self.max_grad_norm, g["betas"], g["eps"],
-                                      self._norms[step:step + 1], grad_scale=1.0 / self.world, rec=self._rec, next_idx=nxt)
+                                      self._norms[step:step + 1], grad_scale=1.0 / self.world, rec=k7_rec, next_idx=nxt)
                     step += 1
                     continue
                 if chain:
-                    ops.mlp_ppo_minibatch(b_obs, b_actions, self._rec, mb_inds, self.bucket.flat_param, self._mlp,
+                    ops.mlp_ppo_minibatch(b_obs, k7_act, k7_rec, mb_inds, self.bucket.flat_param, self._mlp,
                                           self.bucket.flat_grad, self.clip_coeff, self.entropy_coeff, self.value_coeff,
                                           self.norm_adv, vmode, self._scalars[step], self._adam_m, self._adam_v,
                                           self._lr_tensor, self._adam_t, self.max_grad_norm, g["betas"], g["eps"],
@@ -439,7 +446,7 @@ class ppo:
                     continue
                 if packed and self._mlp is not None:
                     # one fused launch: rows are read through the permutation, gradients land in the bucket
-                    ops.mlp_ppo_step(b_obs, b_actions, self._rec, mb_inds, self.bucket.flat_param, self._mlp,
+                    ops.mlp_ppo_step(b_obs, k7_act, k7_rec, mb_inds, self.bucket.flat_param, self._mlp,
                                      self.bucket.flat_grad, self.clip_coeff, self.entropy_coeff, self.value_coeff,
                                      self.norm_adv, vmode, self._scalars[step])
                     D.allreduce_mean_(self.bucket.flat_grad, self.world)
@@ -492,8 +499,9 @@ class ppo:
         if self._probe_mlp_outs is None:
             self._probe_mlp_outs = [torch.empty_like(self.bucket.flat_grad), torch.empty(self.ops.N_SCALARS, device=self.device)]
         vmode = self.ops.VLOSS_CLIPPED if self.clip_vloss else self.ops.VLOSS_OLDVALUES
-        self.ops.mlp_ppo_step(self.buffer.states.reshape((-1,) + self.buffer.observation_shape),
-                              self.buffer.actions.reshape((-1,) + self.buffer.action_shape), self._rec,
+        acts, rec = (None, self._rec64) if self._rec64 is not None else (
+            self.buffer.actions.reshape((-1,) + self.buffer.action_shape), self._rec)
+        self.ops.mlp_ppo_step(self.buffer.states.reshape((-1,) + self.buffer.observation_shape), acts, rec,
                               perms[0][:self.minibatch_size], self.bucket.flat_param, self._mlp, self._probe_mlp_outs[0],
                               self.clip_coeff, self.entropy_coeff, self.value_coeff, self.norm_adv, vmode,
                               self._probe_mlp_outs[1], events=events)

@@ -188,6 +188,13 @@ int aurppo_mlp_ppo_minibatch_f32(const float* obs, const float* actions, const f
                                  double beta1, double beta2, double eps, float* out_norm, const int32_t* next_idx,
                                  int next_M, int chained, void* workspace, void* stream);
 
+/* Packed records.  Every aurppo_mlp_ppo_* entry point accepts actions == NULL: rec is then (B, 16) floats per sample,
+ * {old_logp, A, R, V, action row (at most 12 floats), 0 ...}, built by aurppo_pack_records_f32 from the (B, 4)
+ * records of aurppo_gae_pack_f32 and the (B, action_floats) action buffer.  A sample's record and action row then
+ * share one 64-B line instead of one 128-B line each: 3 lines per sample instead of 4 in K7's gather.            */
+int aurppo_pack_records_f32(const float* rec4, const float* actions, int B, int action_floats, float* rec64,
+                            void* stream);
+
 /* The same minibatch in two halves, for one process per GPU (src/ppo.py:219-269 with a gradient all-reduce between
  * loss.backward() and clip_grad_norm_): aurppo_mlp_ppo_grad_f32 = aurppo_mlp_ppo_step_f32 that also advances the Adam
  * step count (step_dev) and, with chained != 0, skips the preparation the previous apply call already did;
@@ -195,7 +202,8 @@ int aurppo_mlp_ppo_minibatch_f32(const float* obs, const float* actions, const f
  * multiplied by grad_scale (1/world after a SUM all-reduce), its norm is formed inside the kernel (grads itself is
  * left as it was: other workgroups are still reading it), and -- as in
  * aurppo_mlp_ppo_minibatch_f32 -- the statistics of next_idx and the operand copy of the new first layer are
- * prepared for the next aurppo_mlp_ppo_grad_f32(chained = 1) on this workspace.                               */
+ * prepared for the next aurppo_mlp_ppo_grad_f32(chained = 1) on this workspace (rec_floats: 4, or 16 for packed
+ * records, below).                                                                                           */
 int aurppo_mlp_ppo_grad_f32(const float* obs, const float* actions, const float* rec, const int32_t* idx, int M, int D,
                             int A, int continuous, int hidden, const float* params, const int* layout_h, int n_params,
                             float* grads, double clip, double ent_coef, double vf_coef, int norm_adv, int vloss_mode,
@@ -203,7 +211,8 @@ int aurppo_mlp_ppo_grad_f32(const float* obs, const float* actions, const float*
 int aurppo_mlp_ppo_apply_f32(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const int* layout_h,
                              int n_params, int D, double grad_scale, double max_norm, const float* lr_dev,
                              const float* step_dev, double beta1, double beta2, double eps, float* out_norm,
-                             const float* rec, const int32_t* next_idx, int next_M, void* workspace, void* stream);
+                             const float* rec, int rec_floats, const int32_t* next_idx, int next_M, void* workspace,
+                             void* stream);
 
 /* ---- K8: rollout step for the MLP actor-critic -----------------------------------------------------
  * Replaces `action, logprob, _, value = policy.evaluate(next_obs)` under no_grad and the three buffer row

@@ -245,3 +245,48 @@ def test_grad_and_apply_halves_match_the_whole_minibatch(variant):
     torch.testing.assert_close(got[3], ref[3], rtol=1e-6, atol=1e-7)
     for a_, b_ in zip(got[:3], ref[:3]):
         torch.testing.assert_close(a_, b_, rtol=1e-5, atol=1e-7)
+
+
+# ---------------------------------------------------------------------------------- packed 64-byte records
+@pytest.mark.parametrize("cont,D,A", [(True, 64, 6), (True, 11, 12), (False, 8, 5)])
+def test_packed_records_give_identical_results(cont, D, A, variant):
+    """actions == NULL + (B, 16) records from aurppo_pack_records_f32: same gradients and scalars, bit for bit, as the
+    separate action buffer -- through the plain step, the chained minibatch and the two halves."""
+    T, N, M = 16, 64, 300
+    H, pol, bucket, obs, act, rec = _setup(T, N, D, A, seed=6, cont=cont)
+    lay = H.mlp_layout(pol, bucket)
+    nb = bucket.flat_param.numel()
+    rec64 = H.pack_records(rec, act.reshape(T * N, -1))
+    assert rec64.shape == (T * N, 16) and torch.equal(rec64[:, :4], rec)
+    aw = A if cont else 1
+    assert torch.equal(rec64[:, 4:4 + aw], act.reshape(T * N, -1)) and float(rec64[:, 4 + aw:].abs().sum()) == 0.0
+    perm = torch.randperm(T * N, device="cuda").int()
+    slices = [perm[s:s + M] for s in range(0, T * N, M)]
+    p0 = bucket.flat_param.clone()
+
+    def run(packed, mode):
+        bucket.flat_param.copy_(p0)
+        a_, r_ = (None, rec64) if packed else (act, rec)
+        m, v, g = (torch.zeros(nb, device="cuda") for _ in range(3))
+        lr, t = torch.full((1,), 3e-3, device="cuda"), torch.zeros(1, device="cuda")
+        sc, norms = torch.zeros(len(slices), 9, device="cuda"), torch.zeros(len(slices), device="cuda")
+        grads = []
+        for k, idx in enumerate(slices):
+            nxt = slices[k + 1] if k + 1 < len(slices) else None
+            if mode == "step":
+                H.mlp_ppo_step(obs, a_, r_, idx, bucket.flat_param, lay, g, 0.2, 0.01, 0.5, True, 1, sc[k])
+                grads.append(g.clone())
+            elif mode == "chain":
+                H.mlp_ppo_minibatch(obs, a_, r_, idx, bucket.flat_param, lay, g, 0.2, 0.01, 0.5, True, 1, sc[k], m, v, lr, t, 0.5,
+                                    (0.9, 0.999), 1e-5, norms[k:k + 1], next_idx=nxt, chained=k > 0)
+            else:
+                H.mlp_ppo_grad(obs, a_, r_, idx, bucket.flat_param, lay, g, 0.2, 0.01, 0.5, True, 1, sc[k], t, chained=k > 0)
+                H.mlp_ppo_apply(bucket.flat_param, g, m, v, lay, lr, t, 0.5, (0.9, 0.999), 1e-5, norms[k:k + 1], rec=r_, next_idx=nxt)
+        torch.cuda.synchronize()
+        return bucket.flat_param.clone(), sc, norms, grads
+
+    for mode in ("step", "chain", "halves"):
+        ref, got = run(False, mode), run(True, mode)
+        assert torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2]) and torch.equal(got[0], ref[0]), mode
+        for a_, b_ in zip(got[3], ref[3]):
+            assert torch.equal(a_, b_)

@@ -28,14 +28,13 @@ for d in ("$O/pmc_fetch", "$O/pmc_write"):
 fetch = sum(vals["FETCH_SIZE"]) / len(vals["FETCH_SIZE"]) * 1024
 write = sum(vals["WRITE_SIZE"]) / len(vals["WRITE_SIZE"]) * 1024
 M = 131072
-narrow = M * 28          # action row 24 B + index 4 B: 4-B/lane loads, counted exactly
-wide_alg = M * 272       # observation row 256 B + record 16 B: 16-B/lane loads, counted at half
+alg = M * 300           # observation row 256 B + action row 24 B + record 16 B + index 4 B
 res = {"kernel": "k_mlp_step2", "launches": {k: len(v) for k, v in vals.items()},
        "fetch_size_raw_bytes": fetch, "write_size_bytes": write,
        "fetch_corrected_bytes": 2 * fetch, "hbm_bytes_per_launch": 2 * fetch + write,
-       "algorithmic_read_bytes": narrow + wide_alg,
+       "algorithmic_read_bytes": alg,
        "algorithmic_note": "obs 256 B + action 24 B + record 16 B + idx 4 B per sample, read once; writes = gradient slabs (one per workgroup)",
-       "correction": "FETCH_SIZE x2 (MI355X_MICROARCH.md section HBM: gfx950 tallies a 128-B memory-side request at 64 B); WRITE_SIZE exact. Every random access moves whole 128-B lines: observation row 2 lines, 16-B record 1, 24-B action row 1 = 512 B per sample against 300 B algorithmic",
+       "correction": "FETCH_SIZE x2 (MI355X_MICROARCH.md section HBM: gfx950 tallies a 128-B memory-side request at 64 B); WRITE_SIZE exact. Every random access moves whole 128-B lines: observation row 2 lines + packed 64-B record (record and action row) 1 line = 384 B per sample against 300 B algorithmic; with a separate action buffer it was 4 lines, 512 B (r01 history in DESIGN.md)",
        "collected": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of bench.py --steps 2 --warmup 2 --no-probe; mean over the launches; counters in KiB"}
 json.dump(res, open("$O/mlp_pmc.json", "w"), indent=1)
 print(json.dumps(res))
