@@ -49,12 +49,15 @@ def _ptr(t, dtype=torch.float32):
 
 
 _ws_cache = {}
+_ws_retired = []      # outgrown workspaces stay allocated: a captured hipGraph may still point into them
 
 
 def _workspace(kind, nbytes, device):
     key = (kind, device.index if device.index is not None else torch.cuda.current_device())
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
+        if ws is not None:
+            _ws_retired.append(ws)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
         _ws_cache[key] = ws
     return ws
