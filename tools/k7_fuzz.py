@@ -30,7 +30,12 @@ for case in range(n_cases):
     loss.backward()
     g_ref = bucket.flat_grad[:lay["n_params"]].clone()
     g_out = torch.full_like(bucket.flat_grad, float("nan"))
-    sc = H.mlp_ppo_step(obs, act, rec, idx, bucket.flat_param, lay, g_out, 0.2, 0.01, 0.5, norm_adv, vmode)
+    aw = A if cont else 1
+    if aw <= 12 and random.random() < 0.5:      # packed 64-byte records
+        sc = H.mlp_ppo_step(obs, None, H.pack_records(rec, act.reshape(B, -1)), idx, bucket.flat_param, lay, g_out, 0.2, 0.01, 0.5,
+                            norm_adv, vmode)
+    else:
+        sc = H.mlp_ppo_step(obs, act, rec, idx, bucket.flat_param, lay, g_out, 0.2, 0.01, 0.5, norm_adv, vmode)
     torch.cuda.synchronize()
     g = g_out[:lay["n_params"]]
     assert torch.isfinite(g).all(), (case, "non-finite gradient")
