@@ -105,8 +105,12 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
 #endif
     __shared__ int s_next[2][2];                // per set, per iteration parity: does the set have a tile for the next iteration
     __shared__ int s_first[2];                  // per set: is its first tile real
+    __shared__ int s_grab;                      // the workgroup's first grab
     __shared__ int s_bar[2];                    // per set: arrivals at the set's own (software) barriers
 
+#ifdef AURPPO_MLP_STAMPS
+    const unsigned long long rt_entry = wall_clock64();   // timeline of the launch in 10-ns ticks (slots 34..38)
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps set / net / cb and everything derived from them scalar
     const int set = wave >> 2, w = wave & 3, st = tid & (kSetThreads - 1);
@@ -154,49 +158,85 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
     // wave 0 of each set owns the set's tile queue: t1 / t2 = tiles of the next two iterations (wave-uniform),
     // t3_raw = lane 0's pending grab for the one after (an atomic issued one tile ahead of its use)
     int t1 = 0, t2 = 0, t3_raw = 0;
-    // The first grab goes out before anything else (all sets hit one counter: ~a microsecond of round trip when
-    // 496 of them arrive together); its result is only looked at after the weights have been staged.
-    // Priming the queue (tiles of iterations 0..3).  Large minibatches: everything comes from the counter -- one grab
-    // of three consecutive tiles plus a single one -- so a workgroup that starts late owns nothing.  Small ones (under
-    // four tiles per set): a set's first two tiles are fixed (set s of S takes tiles s and s + S) and the counter
-    // starts behind them, because grabs issued back to back by one wave are served back to back and the few tiles
-    // there are would all land in the first sets to arrive (64 tiles on 64 sets took three rounds instead of one).
-    // Either way the grabs go out before anything else: all sets hit one counter, ~a microsecond of round trip when
-    // 496 of them arrive together, which the weight staging hides.
+    // Priming the queue (tiles of iterations 0..3).  Large minibatches: everything comes from the counter, so a
+    // workgroup that starts late owns nothing -- ONE grab of eight consecutive tiles per workgroup, four per set.
+    // (Per-set grabs at kernel entry were ~1000 atomics on one address: stamps showed 8-10 us of every launch waiting
+    // for them, the weight staging included, since a wait for a load also waits for everything issued before it.)
+    // Small minibatches (under four tiles per set): a set's first two tiles are fixed (set s of S takes tiles s and
+    // s + S) and the counter starts behind them, because consecutive grabs land in the first sets to arrive (64 tiles
+    // on 64 sets took three rounds instead of one).  The grab is issued behind the weight loads.
     const int n_sets = 2 * gridDim.x, my_set = 2 * blockIdx.x + set;
     const bool fixed_start = n_tiles < 4 * n_sets;
     const int dyn_base = fixed_start ? 2 * n_sets : 0;   // tile = dyn_base + counter value
-    int g0_raw = 0;
-    if (w == 0 && lane == 0) {
-        g0_raw = (int)atomicAdd(tile_counter + zero_off, fixed_start ? 1u : 3u);
-        t3_raw = (int)atomicAdd(tile_counter + zero_off, 1u);
-    }
-    // ---- stage the shared weights (once per launch)
-    for (int n = 0; n < 2; ++n) {
-        for (int e = tid; e < H * H; e += kThreads2) sW2[(n * H + e / H) * LD + e % H] = a.params[a.L.w2[n] + e];
-        for (int e = tid; e < AP * H; e += kThreads2) {
-            const int o = e / H, i = e % H;
-            sW3[(n * AP + o) * LD + i] = o < out_dim[n] ? a.params[a.L.w3[n] + o * H + i] : 0.0f;
+    int grab_raw = 0;
+    // ---- stage the shared weights (once per launch).  Every global load of the prologue is issued before the first
+    // of them is waited for: section by section (load, wait, store to LDS, next) it was a dozen L2 round trips in a
+    // row with 248 workgroups asking for the same 68 KB -- 17 us of a 174 us launch (stamps: tools/mlp_stamps.py).
+    {
+        float w2r[2][H * H / kThreads2], w3r[2][AP * H / kThreads2], b1r = 0.f, b2r = 0.f, b3r = 0.f, lsr = 0.f;
+        static_assert(H * H % kThreads2 == 0 && AP * H % kThreads2 == 0 && 2 * H <= kThreads2, "staging slots");
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+#pragma unroll
+            for (int q = 0; q < H * H / kThreads2; ++q) w2r[n][q] = a.params[a.L.w2[n] + tid + q * kThreads2];
+#pragma unroll
+            for (int q = 0; q < AP * H / kThreads2; ++q) {
+                const int e = tid + q * kThreads2, o = e / H;
+                w3r[n][q] = a.params[o < out_dim[n] ? a.L.w3[n] + e : a.L.w3[n]];   // rows past the head are zeroed below
+            }
         }
-        for (int e = tid; e < H; e += kThreads2) {
-            sB1[n * H + e] = a.params[a.L.b1[n] + e];
-            sB2[n * H + e] = a.params[a.L.b2[n] + e];
+        // (selects, not a.L.b1[n]: indexing the argument block with a run-time n turns into a vector load of the kernel
+        // arguments and a wait that all the weight loads above queue up behind)
+        if (tid < 2 * H) {
+            const int e = tid % H;
+            b1r = a.params[(tid < H ? a.L.b1[0] : a.L.b1[1]) + e];
+            b2r = a.params[(tid < H ? a.L.b2[0] : a.L.b2[1]) + e];
         }
-        for (int e = tid; e < AP; e += kThreads2) sB3[n * AP + e] = e < out_dim[n] ? a.params[a.L.b3[n] + e] : 0.0f;
-    }
-    for (int e = tid; e < AP; e += kThreads2) {
-        const float ls = (a.continuous && e < A) ? a.params[a.L.logstd + e] : 0.0f;
-        const float sd = expf(ls);
-        sLs[e] = ls;
-        sIvar[e] = 1.0f / (sd * sd);
+        if (tid < 2 * AP) {
+            const int e = tid % AP, od = tid < AP ? A : 1, b3 = tid < AP ? a.L.b3[0] : a.L.b3[1];
+            b3r = a.params[e < od ? b3 + e : b3];
+        }
+        if (tid < AP) lsr = a.params[(a.continuous && tid < A) ? a.L.logstd + tid : a.L.w2[0]];
+        if (tid == 0) grab_raw = (int)atomicAdd(tile_counter + zero_off, fixed_start ? 2u : 8u);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+#pragma unroll
+            for (int q = 0; q < H * H / kThreads2; ++q) {
+                const int e = tid + q * kThreads2;
+                sW2[(n * H + e / H) * LD + e % H] = w2r[n][q];
+            }
+#pragma unroll
+            for (int q = 0; q < AP * H / kThreads2; ++q) {
+                const int e = tid + q * kThreads2, o = e / H, i = e % H;
+                sW3[(n * AP + o) * LD + i] = o < out_dim[n] ? w3r[n][q] : 0.0f;
+            }
+        }
+        if (tid < 2 * H) {
+            sB1[tid] = b1r;
+            sB2[tid] = b2r;
+        }
+        if (tid < 2 * AP) sB3[tid] = (tid % AP) < (tid < AP ? A : 1) ? b3r : 0.0f;
+        if (tid < AP) {
+            const float ls = (a.continuous && tid < A) ? lsr : 0.0f;
+            const float sd = expf(ls);
+            sLs[tid] = ls;
+            sIvar[tid] = 1.0f / (sd * sd);
+        }
     }
     for (int e = st; e < R * LD; e += kSetThreads) sX[e] = 0.0f;   // columns >= D stay zero for the whole launch
     for (int e = tid; e < 2 * 6 * R; e += kThreads2) (&s_loss[0][0][0])[e] = 0.0;
+    if (tid == 0) s_grab = grab_raw;
+    __syncthreads();
     if (w == 0) {
-        const int g0 = __builtin_amdgcn_readfirstlane(g0_raw);
-        const int base = fixed_start ? my_set : g0;
-        t1 = fixed_start ? my_set + n_sets : g0 + 1;
-        t2 = fixed_start ? dyn_base + g0 : g0 + 2;
+        const int g = s_grab;
+        const int base = fixed_start ? my_set : g + 4 * set;
+        t1 = fixed_start ? my_set + n_sets : base + 1;
+        t2 = fixed_start ? dyn_base + g + set : base + 2;
+        if (fixed_start) {
+            if (lane == 0) t3_raw = (int)atomicAdd(tile_counter + zero_off, 1u);   // consumed a tile later
+        } else {
+            t3_raw = base + 3;
+        }
         if (lane == 0) {
             s_first[set] = base < n_tiles ? 1 : 0;
             s_bar[set] = 0;
@@ -553,7 +593,13 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
         STAMP2(15);
         if (!s_next[set][it & 1]) break;     // written by the set's wave 0 in this iteration's S phase
     }
+#ifdef AURPPO_MLP_STAMPS
+    const unsigned long long rt_loop_end = wall_clock64();
+#endif
     __syncthreads();   // the hand-over below reuses the weights' LDS: both sets must have left the loop
+#ifdef AURPPO_MLP_STAMPS
+    const unsigned long long rt_both_done = wall_clock64();
+#endif
 
     int le = lane, se = st;   // fresh opaque copies: nothing lane-derived has to stay live across the tile loop
     asm volatile("" : "+v"(le), "+v"(se));
@@ -652,6 +698,11 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
     if (tid == 0) {   // shader cycles and 100 MHz wall-clock ticks of the tile loop + hand-over: the clock the launch ran at
         a.stamps[(size_t)blockIdx.x * 40 + 32] = __builtin_readcyclecounter() - clk0;
         a.stamps[(size_t)blockIdx.x * 40 + 33] = wall_clock64() - rt0;
+        a.stamps[(size_t)blockIdx.x * 40 + 34] = rt_entry;          // absolute: launch skew between workgroups
+        a.stamps[(size_t)blockIdx.x * 40 + 35] = rt0 - rt_entry;     // prologue (weights, statistics, queue, first fetch)
+        a.stamps[(size_t)blockIdx.x * 40 + 36] = rt_loop_end - rt0;  // set 0 / wave 0's tile loop
+        a.stamps[(size_t)blockIdx.x * 40 + 37] = rt_both_done - rt_loop_end;   // waiting for the other set
+        a.stamps[(size_t)blockIdx.x * 40 + 38] = wall_clock64() - rt_both_done;  // hand-over + slab write (issue)
     }
 #endif
 }

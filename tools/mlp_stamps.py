@@ -39,9 +39,15 @@ if variant == "1":
     print("total cycles (wave 0, median WG):", tot, " tiles per WG:", M // 32 // 256)
 else:
     raw = ws[off:off + 8 * 40 * 256].view(torch.int64).view(256, 40).cpu().numpy().astype(np.float64)
-    raw = raw[raw[:, 1] > 0]
+    raw = raw[(raw[:, 1] > 0) & (raw[:, 35] > 0) & (raw[:, 35] < 1e6) & (raw[:, 36] > 0) & (raw[:, 36] < 1e7)]   # workgroups of this launch
     cyc, ticks = np.median(raw[:, 32]), np.median(raw[:, 33])
     print(f"shader clock over the tile loop + hand-over: {cyc:.0f} cycles in {ticks:.0f} ticks of the 100 MHz wall clock = {cyc / ticks * 0.1:.2f} GHz")
+    ent = raw[:, 34]
+    print(f"launch timeline (10-ns ticks of the wall clock, over {raw.shape[0]} workgroups): first-to-last workgroup entry "
+          f"{(ent.max() - ent.min()) / 100:.1f} us; medians: prologue {np.median(raw[:, 35]) / 100:.1f} us, tile loop "
+          f"{np.median(raw[:, 36]) / 100:.1f} us (min {raw[:, 36].min() / 100:.1f}, max {raw[:, 36].max() / 100:.1f}), wait for the "
+          f"other set {np.median(raw[:, 37]) / 100:.1f} us, hand-over + slab {np.median(raw[:, 38]) / 100:.1f} us; "
+          f"last exit - first entry {((ent + raw[:, 35:39].sum(1)).max() - ent.min()) / 100:.1f} us")
     st = raw[:, :32].reshape(-1, 2, 16)
     names = ["S  land tile, prefetch", "F1 layer 1 + tanh", "F2 layer 2 + tanh", "F3 head", "L  loss lanes", "B1 dH2,dW3,dZ2",
              "B2 dW2,dH1,dZ1", "B3 dW1"]
