@@ -529,7 +529,12 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
             const float* W3 = sW3 + net * AP * LD;
             float* H2 = sH2 + net * R * LD;
             f32x16 acc = zero16();
-            mma32<AP, kCh, true>(acc, [&](int i, int k) { return dO[i * LDO + k]; }, [&](int k, int j) { return W3[k * LD + cb * 32 + j]; }, ln);
+            // dH2 = dO . W3 over the head's outputs: columns past the head width are zero, so K = 8 covers a head of up to
+            // 8 outputs (and the critic's single one) with half the matrix instructions of the padded 16
+            if (A <= 8 || net == 1)
+                mma32<8, kCh, true>(acc, [&](int i, int k) { return dO[i * LDO + k]; }, [&](int k, int j) { return W3[k * LD + cb * 32 + j]; }, ln);
+            else
+                mma32<AP, kCh, true>(acc, [&](int i, int k) { return dO[i * LDO + k]; }, [&](int k, int j) { return W3[k * LD + cb * 32 + j]; }, ln);
             // dW3 (AP rows) x (in-block cb) as two 16x16 blocks: A = dO^T, B = H2 (still the activations) -- a 32x32 MFMA
             // block would spend half its rows on padding
 #pragma unroll

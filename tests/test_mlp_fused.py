@@ -40,7 +40,7 @@ def variant(request, monkeypatch):
 
 @pytest.mark.parametrize("T,N,D,A,M", [(8, 64, 64, 6, 256), (16, 64, 64, 6, 1000), (4, 32, 4, 1, 77), (8, 32, 32, 16, 128),
                                          (8, 32, 6, 3, 100), (8, 64, 10, 9, 31), (8, 32, 3, 1, 100), (8, 64, 11, 3, 333),
-                                         (16, 64, 17, 6, 1000), (128, 1024, 64, 6, 131072)])
+                                         (16, 64, 17, 6, 1000), (8, 32, 16, 8, 100), (128, 1024, 64, 6, 131072)])
 @pytest.mark.parametrize("norm_adv,vmode", [(True, 1), (False, 2), (True, 0)])
 def test_fused_step_matches_autograd_path(T, N, D, A, M, norm_adv, vmode, variant):
     H, pol, bucket, obs, act, rec = _setup(T, N, D, A)
