@@ -18,8 +18,14 @@ __device__ __forceinline__ AdamScalars adam_scalars(const double* __restrict__ p
                                                     const float* __restrict__ lr_dev, const float* __restrict__ step,
                                                     double beta1, double beta2, double eps, float* __restrict__ out_norm,
                                                     bool write_norm, double* sc, float* s_coef) {
+    // the step count and the learning rate are fetched, and the bias corrections formed, while the partial sums are
+    // still on their way: one memory round trip for the whole preamble instead of two
+    const double tt = (double)*step;
+    const double lr = (double)*lr_dev;
     double q = 0.0;
     for (int b = threadIdx.x; b < n_part; b += blockDim.x) q += part[b];
+    const double bc1 = 1.0 - pow(beta1, tt);
+    const double bc2 = 1.0 - pow(beta2, tt);
     const double t = block_sum<NW>(q, sc);
     if (threadIdx.x == 0) {
         const float norm = (float)sqrt(t);
@@ -32,16 +38,29 @@ __device__ __forceinline__ AdamScalars adam_scalars(const double* __restrict__ p
     AdamScalars a;
     a.coef = *s_coef;
     a.gscale = 1.0f;
-    const double tt = (double)*step;
-    const double bc1 = 1.0 - pow(beta1, tt);
-    const double bc2 = 1.0 - pow(beta2, tt);
-    a.step_size = (float)((double)*lr_dev / bc1);
+    a.step_size = (float)(lr / bc1);
     a.bc2_sqrt = (float)sqrt(bc2);
     a.w1 = (float)(1.0 - beta1);
     a.b2 = (float)beta2;
     a.w2 = (float)(1.0 - beta2);
     a.eps = (float)eps;
     return a;
+}
+
+// adam_update (below) on operands the caller has already fetched (so that the loads overlap the clip preamble)
+__device__ __forceinline__ float adam_update_pre(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                 float* __restrict__ v, int64_t i, float p0, float g0, float m0, float v0,
+                                                 const AdamScalars& a, bool store_g) {
+    const float gi = (g0 * a.gscale) * a.coef;
+    if (store_g) g[i] = gi;
+    const float mi = m0 + a.w1 * (gi - m0);
+    const float vi = v0 * a.b2 + (a.w2 * gi) * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / a.bc2_sqrt + a.eps;
+    const float pn = p0 - a.step_size * (mi / denom);
+    p[i] = pn;
+    return pn;
 }
 
 // m.lerp_(g, 1-b1); v = v*b2 + (1-b2)*g*g; p -= step_size * m / (sqrt(v)/sqrt(1-b2^t) + eps); returns the new p

@@ -617,16 +617,19 @@ __global__ __launch_bounds__(1024) void k_mlp_reduce(const float* __restrict__ s
     const int p = blockIdx.x * 64 + pi;
     float acc = 0.0f;
     if (p < n_params) {
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        int b = grp;
-        for (; b + 3 * kRedGroups < n_slabs; b += 4 * kRedGroups) {
-            a0 += slabs[(size_t)b * n_params + p];
-            a1 += slabs[(size_t)(b + kRedGroups) * n_params + p];
-            a2 += slabs[(size_t)(b + 2 * kRedGroups) * n_params + p];
-            a3 += slabs[(size_t)(b + 3 * kRedGroups) * n_params + p];
+        // n_slabs <= kMaxGrid = 16 groups x 16: a thread's rows are all fetched before the first add (one memory round
+        // trip, not four); rows past n_slabs read as zero; the order of the adds is fixed
+        static_assert(kMaxGrid <= 16 * kRedGroups, "k_mlp_reduce: 16 rows per thread cover the grid");
+        float x[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int b = grp + j * kRedGroups;
+            x[j] = b < n_slabs ? slabs[(size_t)b * n_params + p] : 0.0f;
         }
-        for (; b < n_slabs; b += kRedGroups) a0 += slabs[(size_t)b * n_params + p];
-        acc = (a0 + a1) + (a2 + a3);
+        float a4[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a4[k] = ((x[k] + x[k + 4]) + x[k + 8]) + x[k + 12];
+        acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
     }
     s_part[grp][pi] = acc;
     __syncthreads();
@@ -688,6 +691,19 @@ __global__ __launch_bounds__(kThreads) void k_adam_chain(float* __restrict__ p, 
     __shared__ float s_coef;
     if ((int)blockIdx.x < nb_upd) {
         __shared__ double s_own;
+        // a thread's first four elements are fetched before the clip preamble, whose partial sums, block reductions
+        // and pow() calls they then overlap
+        constexpr int kPre = 4;
+        float p0[kPre], g0[kPre], m0[kPre], v0[kPre];
+#pragma unroll
+        for (int k = 0; k < kPre; ++k) {
+            const int i = (blockIdx.x + k * nb_upd) * kThreads + threadIdx.x;
+            const bool ok = i < n;
+            p0[k] = ok ? p[i] : 0.0f;
+            g0[k] = ok ? g[i] : 0.0f;
+            m0[k] = ok ? m[i] : 0.0f;
+            v0[k] = ok ? v[i] : 0.0f;
+        }
         if (!part) {
             // no partial sums were left by k_mlp_reduce (the gradient went through an all-reduce since): every
             // workgroup forms the norm of the scaled gradient itself, in the same order -- 17 k floats, L2-resident
@@ -703,8 +719,19 @@ __global__ __launch_bounds__(kThreads) void k_adam_chain(float* __restrict__ p, 
         AdamScalars a = adam_scalars<kThreads / kWave>(part ? part : &s_own, part ? n_part : 1, max_norm, lr_dev, step, beta1,
                                                        beta2, eps, out_norm, blockIdx.x == 0, sc[0], &s_coef);
         a.gscale = gscale;
-        for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += nb_upd * kThreads) {
-            const float pn = adam_update(p, g, m, v, i, true, a, part != nullptr);   // in-kernel norm: g is still being read
+        int k = 0;
+        for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += nb_upd * kThreads, ++k) {
+            // in-kernel norm: g is still being read by the other workgroups, so the clipped value is not stored back
+            float pn;
+            if (k < kPre) {
+                float pk = p0[0], gk = g0[0], mk = m0[0], vk = v0[0];
+#pragma unroll
+                for (int j = 1; j < kPre; ++j)
+                    if (k == j) { pk = p0[j]; gk = g0[j]; mk = m0[j]; vk = v0[j]; }
+                pn = adam_update_pre(p, g, m, v, i, pk, gk, mk, vk, a, part != nullptr);
+            } else {
+                pn = adam_update(p, g, m, v, i, true, a, part != nullptr);
+            }
             const int ea = i - w1_actor, ec = i - w1_critic;
             const int e = (ea >= 0 && ea < H * D) ? ea : ((ec >= 0 && ec < H * D) ? ec : -1);
             if (e >= 0) {

@@ -73,7 +73,8 @@ def test_fused_step_matches_autograd_path(T, N, D, A, M, norm_adv, vmode, varian
         k = p_.numel()
         a, b = g[off:off + k], g_ref[off:off + k]
         s = float(b.abs().max())
-        assert float((a - b).abs().max()) <= 5e-5 * s + 1e-9, (nm, float((a - b).abs().max()), s)
+        # floor: a bias gradient is a sum of M terms that may cancel to far below the terms' own rounding error
+        assert float((a - b).abs().max()) <= 5e-5 * s + 2e-6 * scale + 1e-9, (nm, float((a - b).abs().max()), s)
         off += k
 
 
