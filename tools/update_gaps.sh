@@ -16,6 +16,11 @@ gaps = {}
 for a, b in zip(rows, rows[1:]):
     g = (int(b["Start_Timestamp"]) - int(a["End_Timestamp"])) / 1e3
     if g < 200: gaps.setdefault((short(a["Kernel_Name"]), short(b["Kernel_Name"])), []).append(g)
+dur = {}
+for r in rows:
+    dur.setdefault(short(r["Kernel_Name"]), []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+for k, v in dur.items():
+    print(f"{k:14s} n={len(v):4d} duration median {st.median(v):7.2f} us  min {min(v):7.2f} us")
 for k, v in sorted(gaps.items(), key=lambda kv: -len(kv[1])):
     if len(v) >= 10: print(f"{k[0]:14s} -> {k[1]:14s} n={len(v):4d} gap median {st.median(v):6.2f} us  mean {st.mean(v):6.2f} us")
 PY
