@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--act-dim", type=int, default=6)
     ap.add_argument("--epochs", type=int, default=4)
     ap.add_argument("--minibatches", type=int, default=4)
-    ap.add_argument("--cpu-baseline-updates", type=int, default=2, help="timed CPU-oracle updates (0 = skip)")
+    ap.add_argument("--cpu-baseline-updates", type=int, default=4, help="timed CPU-oracle updates (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = usable cores, <=16)")
     ap.add_argument("--no-probe", action="store_true", help="do not time the gather kernel with HIP events")
     ap.add_argument("--no-graph", action="store_true", help="run the update eagerly instead of as a hipGraph")
