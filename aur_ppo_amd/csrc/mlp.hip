@@ -707,8 +707,26 @@ __global__ __launch_bounds__(kThreads) void k_adam_chain(float* __restrict__ p, 
         if (!part) {
             // no partial sums were left by k_mlp_reduce (the gradient went through an all-reduce since): every
             // workgroup forms the norm of the scaled gradient itself, in the same order -- 17 k floats, L2-resident
+            // 16-B loads, all of a thread's in flight before the first add (n = 17 k: 17 per thread)
             double q = 0.0;
-            for (int i = threadIdx.x; i < n; i += kThreads) {
+            const int n4 = (reinterpret_cast<uintptr_t>(g) & 15) == 0 ? n / 4 : 0;
+            const float4* g4 = reinterpret_cast<const float4*>(g);
+            constexpr int kU = 8;
+            for (int i0 = threadIdx.x; i0 < n4; i0 += kU * kThreads) {
+                float4 x[kU];
+#pragma unroll
+                for (int u = 0; u < kU; ++u) {
+                    const int i = i0 + u * kThreads;
+                    x[u] = i < n4 ? g4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < kU; ++u) {
+                    const double a0 = (double)(x[u].x * gscale), a1 = (double)(x[u].y * gscale);
+                    const double a2 = (double)(x[u].z * gscale), a3 = (double)(x[u].w * gscale);
+                    q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+                }
+            }
+            for (int i = 4 * n4 + threadIdx.x; i < n; i += kThreads) {
                 const double x = (double)(g[i] * gscale);
                 q += x * x;
             }
