@@ -107,6 +107,7 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
     __shared__ int s_first[2];                  // per set: is its first tile real
     __shared__ int s_grab;                      // the workgroup's first grab
     __shared__ int s_bar[2];                    // per set: arrivals at the set's own (software) barriers
+    __shared__ int s_pbar[2][2];                // per set and net: arrivals at the barriers only a net's two waves share
 
 #ifdef AURPPO_MLP_STAMPS
     const unsigned long long rt_entry = wall_clock64();   // timeline of the launch in 10-ns ticks (slots 34..38)
@@ -240,6 +241,8 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
         if (lane == 0) {
             s_first[set] = base < n_tiles ? 1 : 0;
             s_bar[set] = 0;
+            s_pbar[set][0] = 0;
+            s_pbar[set][1] = 0;
         }
         const int i0 = load_idx(base, st), i1 = load_idx(t1, st);
         n_idx = load_idx(t2, st);
@@ -360,6 +363,18 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
             __builtin_amdgcn_s_sleep(1);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     };
+    // Between the layers of one net only that net's two waves exchange data (each writes its column half of H1 / H2 /
+    // dZ2 / dZ1, both read all of it): those four barriers involve two waves, not four, and the actor and critic pairs
+    // drift apart between the set-wide barriers around S and L.
+    int pbar_gen = 0;
+    auto pair_bar = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) (void)__hip_atomic_fetch_add(&s_pbar[set][net], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        pbar_gen += 2;
+        while (__hip_atomic_load(&s_pbar[set][net], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - pbar_gen < 0)
+            __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
     for (int it = 0; s_first[set] != 0; ++it) {
         // Opaque per-tile copies of the lane coordinates: every LDS address below is re-derived from them inside
         // the phase (one or two VALU ops) instead of being hoisted out of the loop as ~100 loop-invariant
@@ -424,7 +439,7 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
             for (int e = 0; e < 16; ++e) sH1[(net * R + acc_row(e, ln)) * LD + col] = tanh_fast(acc[e] + bias);
         }
         STAMP2(1);
-        set_bar();
+        pair_bar();
         STAMP2(9);
         {   // ---- F2
             f32x16 acc = zero16();
@@ -437,7 +452,7 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
             for (int e = 0; e < 16; ++e) sH2[(net * R + acc_row(e, ln)) * LD + col] = tanh_fast(acc[e] + bias);
         }
         STAMP2(2);
-        set_bar();
+        pair_bar();
         STAMP2(10);
         {   // ---- F3: head (R x AP), each wave of a net takes 16 of the 32 rows
             const float* W = sW3 + net * AP * LD;
@@ -555,7 +570,7 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
             gb2 += colsum;
         }
         STAMP2(5);
-        set_bar();
+        pair_bar();
         STAMP2(13);
         {   // ---- B2: dW2, dH1 -> dZ1 (in place over this wave's half of H1)
             const float* dZ = sH2 + net * R * LD;
@@ -581,7 +596,7 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
             gb1 += colsum;
         }
         STAMP2(6);
-        set_bar();
+        pair_bar();
         STAMP2(14);
         {   // ---- B3: dW1 (two out-blocks x in-block cb of D)
             if (cb * 32 < D) {
