@@ -458,10 +458,27 @@ __global__ __launch_bounds__(kAccThreads) void k_fy_accept(const uint32_t* __res
 
 __global__ void k_fy_link(const int32_t* __restrict__ j, int32_t* __restrict__ head, int32_t* __restrict__ next,
                           int n) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s < 1 || s >= n) return;
-    const int js = j[s];
-    if (js != s) next[s] = atomicExch(&head[js], s);
+    // grid-stride, four positions per pass: their swaps are in flight together (a memory-side atomic takes ~1 us)
+    constexpr int kB = 4;
+    const int stride = gridDim.x * blockDim.x;
+    for (int s0 = blockIdx.x * blockDim.x + threadIdx.x; s0 < n; s0 += kB * stride) {
+        int js[kB], old[kB];
+#pragma unroll
+        for (int u = 0; u < kB; ++u) {
+            const int s = s0 + u * stride;
+            js[u] = (s >= 1 && s < n) ? j[s] : s;
+        }
+#pragma unroll
+        for (int u = 0; u < kB; ++u) {
+            const int s = s0 + u * stride;
+            old[u] = (s >= 1 && s < n && js[u] != s) ? atomicExch(&head[js[u]], s) : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < kB; ++u) {
+            const int s = s0 + u * stride;
+            if (s >= 1 && s < n && js[u] != s) next[s] = old[u];
+        }
+    }
 }
 
 // out[i] = in[src(i)] (in == nullptr: identity), src(i) = position whose ORIGINAL content ends at i.
@@ -589,7 +606,17 @@ int permute_once(aurppo_rng* rng, const int32_t* in, int32_t* out, int n, hipStr
     AURPPO_HIP_TRY(hipEventRecord(rng->ev_acc[slot], s));
     AURPPO_HIP_TRY(hipMemsetAsync(rng->d_head, 0xff, sizeof(int32_t) * (size_t)n, s));
     const int grid = (n + 255) / 256;
-    hipLaunchKernelGGL(k_fy_link, dim3(grid), dim3(256), 0, s, rng->d_j, rng->d_head, rng->d_next, n);
+    // k_fy_link strides over the positions with a bounded grid.  It runs beside K7, whose workgroups fill the register
+    // file of every CU but the spare ones, so a few dozen workgroups are all that is ever resident; one workgroup per
+    // 256 positions (2048 of them at B = 524 288) cost every K7 launch it overlapped 8-10 us (rocprof,
+    // tools/k7_overlap.sh): 2.73 -> 2.68 ms per update with 48.  AURPPO_K2_LINK_WGS overrides (0 = one per 256).
+    static int link_wgs = -1;
+    if (link_wgs < 0) {
+        const char* e = getenv("AURPPO_K2_LINK_WGS");
+        link_wgs = e && *e ? atoi(e) : 48;
+    }
+    hipLaunchKernelGGL(k_fy_link, dim3(link_wgs > 0 && link_wgs < grid ? link_wgs : grid), dim3(256), 0, s, rng->d_j, rng->d_head,
+                       rng->d_next, n);
     AURPPO_LAUNCH_CHECK("k_fy_link");
     hipLaunchKernelGGL(k_fy_resolve, dim3(grid), dim3(256), 0, s, rng->d_j, rng->d_head, rng->d_next, in, out, n);
     AURPPO_LAUNCH_CHECK("k_fy_resolve");
