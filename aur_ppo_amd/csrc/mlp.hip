@@ -113,7 +113,8 @@ __global__ __launch_bounds__(256, 1) void k_mlp_step(const MlpArgs a) {
         for (int e = tid; e < H * H; e += kThreads) sW2[(n * H + e / H) * LD + e % H] = a.params[a.L.w2[n] + e];
         for (int e = tid; e < AP * H; e += kThreads) {
             const int o = e / H, i = e % H;
-            sW3[(n * AP + o) * LD + i] = o < out_dim[n] ? a.params[a.L.w3[n] + o * H + i] : 0.0f;
+            const float w3v = a.params[a.L.w3[n] + (o < out_dim[n] ? o : 0) * H + i];
+            sW3[(n * AP + o) * LD + i] = o < out_dim[n] ? w3v : 0.0f;
         }
         for (int e = tid; e < H; e += kThreads) {
             sB1[n * H + e] = a.params[a.L.b1[n] + e];
@@ -505,25 +506,45 @@ __global__ __launch_bounds__(256, 1) void k_mlp_act(const ActArgs a) {
     const int D = a.D, A = a.A;
     const int out_dim[2] = {A, 1};
     const int row0 = blockIdx.x * R;
-    for (int e = tid; e < R * LD; e += kThreads) sX[e] = 0.0f;
-    for (int e = tid; e < 2 * H * LD; e += kThreads) sW1[e] = 0.0f;
-    __syncthreads();
-    for (int e = tid; e < R * D; e += kThreads) {
-        const int r = e / D, c = e % D;
-        if (row0 + r < a.N) sX[r * LD + c] = a.obs[(size_t)(row0 + r) * D + c];
+    // Staging: every element's address comes from shifts of a flat index over rows padded to 64 columns (no division,
+    // no zero-fill pass), and all of a thread's loads are independent, so they go out together -- the kernel is a
+    // latency chain (launch, staging, three layers, sampling) and this was its longest link.
+    float* sLs = sB3 + 2 * AP;          // [AP] log-std
+    float* sSd = sLs + AP;              // [AP] exp(log-std)
+#pragma unroll
+    for (int u = 0; u < R * H / kThreads; ++u) {
+        const int e = tid + u * kThreads, r = e >> 6, c = e & 63;
+        // branch-free: a padding lane reads a clamped (valid) element and masks it -- a load under a divergent
+        // condition makes the compiler wait for everything in flight
+        const int rr = row0 + r < a.N ? row0 + r : a.N - 1, cc = c < D ? c : D - 1;
+        const float x = a.obs[(size_t)rr * D + cc];
+        sX[r * LD + c] = (c < D && row0 + r < a.N) ? x : 0.0f;
     }
+#pragma unroll
     for (int n = 0; n < 2; ++n) {
-        for (int e = tid; e < H * D; e += kThreads) sW1[(n * H + e / D) * LD + e % D] = a.params[a.L.w1[n] + e];
-        for (int e = tid; e < H * H; e += kThreads) sW2[(n * H + e / H) * LD + e % H] = a.params[a.L.w2[n] + e];
-        for (int e = tid; e < AP * H; e += kThreads) {
-            const int o = e / H, i = e % H;
+#pragma unroll
+        for (int u = 0; u < H * H / kThreads; ++u) {
+            const int e = tid + u * kThreads, o = e >> 6, c = e & 63;
+            const float w1v = a.params[a.L.w1[n] + o * D + (c < D ? c : D - 1)];
+            const float w2v = a.params[a.L.w2[n] + e];
+            sW1[(n * H + o) * LD + c] = c < D ? w1v : 0.0f;
+            sW2[(n * H + o) * LD + c] = w2v;
+        }
+#pragma unroll
+        for (int u = 0; u < AP * H / kThreads; ++u) {
+            const int e = tid + u * kThreads, o = e >> 6, i = e & 63;
             sW3[(n * AP + o) * LD + i] = o < out_dim[n] ? a.params[a.L.w3[n] + o * H + i] : 0.0f;
         }
-        for (int e = tid; e < H; e += kThreads) {
-            sB1[n * H + e] = a.params[a.L.b1[n] + e];
-            sB2[n * H + e] = a.params[a.L.b2[n] + e];
+        if (tid < H) {
+            sB1[n * H + tid] = a.params[a.L.b1[n] + tid];
+            sB2[n * H + tid] = a.params[a.L.b2[n] + tid];
         }
-        for (int e = tid; e < AP; e += kThreads) sB3[n * AP + e] = e < out_dim[n] ? a.params[a.L.b3[n] + e] : 0.0f;
+        if (tid < AP) sB3[n * AP + tid] = tid < out_dim[n] ? a.params[a.L.b3[n] + tid] : 0.0f;
+    }
+    if (tid < AP) {
+        const float ls = (a.continuous && tid < A) ? a.params[a.L.logstd + tid] : 0.0f;
+        sLs[tid] = ls;
+        sSd[tid] = expf(ls);
     }
     __syncthreads();
     {
@@ -558,6 +579,31 @@ __global__ __launch_bounds__(256, 1) void k_mlp_act(const ActArgs a) {
         for (int e = 0; e < 4; ++e) sOut[(net * R + cb * 16 + 4 * (lane >> 4) + e) * LDO + col] = acc[e] + bias;
     }
     __syncthreads();
+    if (a.noise && a.continuous) {
+        // 8 lanes per row, action dims lj and lj + 8 per lane; the log-prob terms are formed as evaluate() forms them
+        // and folded with DPP moves
+        const int r = tid >> 3, lj = tid & 7, n = row0 + r;
+        const bool live = n < a.N;
+        const float* mu = sOut + r * LDO;
+        float lp = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int k = lj + 8 * q;
+            if (live && k < A) {
+                const float ls = sLs[k], sd = sSd[k], m = mu[k];
+                const float act = m + sd * a.noise[(size_t)n * A + k];
+                a.actions[(size_t)n * A + k] = act;
+                const float z = act - m;                                   // as evaluate() forms it: (a - mu)
+                lp += (-(z * z) / (2.0f * (sd * sd)) - ls) - 0.9189385332046727f;
+            }
+        }
+        lp = sum8(lp);
+        if (live && lj == 0) {
+            a.logp[n] = lp;
+            a.value[n] = sOut[(R + r) * LDO];
+        }
+        return;
+    }
     if (tid < R && row0 + tid < a.N) {
         const int n = row0 + tid;
         const float* mu = sOut + tid * LDO;
@@ -599,7 +645,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_act(const ActArgs a) {
 }
 
 constexpr size_t act_lds_bytes() {
-    return sizeof(float) * (size_t)(R * LD + 2 * 2 * R * LD + 2 * 2 * H * LD + 2 * AP * LD + 2 * R * LDO + 4 * H + 2 * AP);
+    return sizeof(float) * (size_t)(R * LD + 2 * 2 * R * LD + 2 * 2 * H * LD + 2 * AP * LD + 2 * R * LDO + 4 * H + 2 * AP + 2 * AP);
 }
 
 // grads[p] = sum over slabs, fixed order (deterministic); block 0 also folds the loss scalars.

@@ -69,24 +69,6 @@ static_assert(kSharedFloats % 4 == 0 && pRec % 4 == 0 && kSetFloats % 4 == 0, "f
 constexpr int kAccRegs = 72;                 // gW1 (32) + gW2 (32) + gW3 (2 x 4) per lane
 static_assert(kSharedFloats + 2 * kSetFloats >= 4 * kAccRegs * kWave, "hand-over scratch must fit the dead tiles");
 
-// All-reduce over aligned groups of 8 lanes with DPP moves (no LDS traffic): lane i <- i ^ 7 (row_half_mirror),
-// then i ^ 1 and i ^ 2 (quad_perm) -- together every lane has combined all 8.
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float sum8(float v) {
-    v += dpp_mov<0x141>(v);
-    v += dpp_mov<0xB1>(v);
-    v += dpp_mov<0x4E>(v);
-    return v;
-}
-__device__ __forceinline__ float max8(float v) {
-    v = fmaxf(v, dpp_mov<0x141>(v));
-    v = fmaxf(v, dpp_mov<0xB1>(v));
-    v = fmaxf(v, dpp_mov<0x4E>(v));
-    return v;
-}
 // LDS accumulate without reading the result back (ds_add_f64)
 __device__ __forceinline__ void lds_add(double* p, double v) {
     (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

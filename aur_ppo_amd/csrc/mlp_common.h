@@ -127,6 +127,24 @@ __device__ __forceinline__ float tanh_fast(float x) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
 
+// All-reduce over aligned groups of 8 lanes with DPP moves (no LDS traffic): lane i <- i ^ 7 (row_half_mirror),
+// then i ^ 1 and i ^ 2 (quad_perm) -- together every lane has combined all 8.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float sum8(float v) {
+    v += dpp_mov<0x141>(v);
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    return v;
+}
+__device__ __forceinline__ float max8(float v) {
+    v = fmaxf(v, dpp_mov<0x141>(v));
+    v = fmaxf(v, dpp_mov<0xB1>(v));
+    v = fmaxf(v, dpp_mov<0x4E>(v));
+    return v;
+}
 __device__ __forceinline__ f32x16 zero16() {
     f32x16 z;
 #pragma unroll
