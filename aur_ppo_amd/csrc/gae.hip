@@ -41,28 +41,34 @@ __global__ __launch_bounds__(256) void k_gae(const float* __restrict__ rewards, 
     for (int t_hi = T; t_hi > 0; t_hi -= kSlab) {
         const int t_lo = t_hi > kSlab ? t_hi - kSlab : 0;
         const int len = t_hi - t_lo;
-        // ---- phase 1: d, c for the slab
+        // ---- phase 1: d, c for the slab.  All of a thread's loads are issued before the first use (a full slab is
+        // kSlab / ROWS passes of 3-4 loads, unrolled): one memory round trip instead of one per pass.
         if (valid) {
-            for (int tt = tr; tt < len; tt += ROWS) {
-                const int t = t_lo + tt;
+            constexpr int kPass = kSlab / ROWS;
+            float rt[kPass], vt[kPass], nv[kPass], nd[kPass];
+#pragma unroll
+            for (int u = 0; u < kPass; ++u) {
+                const int tt = tr + u * ROWS;
+                const int t = t_lo + (tt < len ? tt : len - 1);      // clamped: padding passes re-read the last row
                 const size_t at = (size_t)t * N + n;
-                const float rt = rewards[at];
-                const float vt = values[at];
-                float nv, nd;
-                if (t == T - 1) {
-                    nv = next_value[n];
-                    nd = next_done[n];
-                } else {
-                    nv = values[at + N];
-                    nd = terminals[at + N];
-                }
-                const float nnt = 1.0f - nd;
+                rt[u] = rewards[at];
+                vt[u] = values[at];
+                const bool last = t == T - 1;
+                nv[u] = last ? next_value[n] : values[at + N];
+                nd[u] = last ? next_done[n] : terminals[at + N];
+            }
+#pragma unroll
+            for (int u = 0; u < kPass; ++u) {
+                const int tt = tr + u * ROWS;
+                if (tt >= len) continue;
+                const int t = t_lo + tt;
+                const float nnt = 1.0f - nd[u];
                 float d_, c_;
                 if (normal) {
-                    d_ = rt;
+                    d_ = rt[u];
                     c_ = g * nnt;
                 } else {
-                    d_ = (rt + (g * nv) * nnt) - vt;
+                    d_ = (rt[u] + (g * nv[u]) * nnt) - vt[u];
                     c_ = gl * nnt;
                     if (mode == AURPPO_GAE_SKIP_LAST && t == T - 1) {
                         d_ = 0.0f;
@@ -71,7 +77,7 @@ __global__ __launch_bounds__(256) void k_gae(const float* __restrict__ rewards, 
                 }
                 s_d[tt][e] = d_;
                 s_c[tt][e] = c_;
-                s_v[tt][e] = vt;
+                s_v[tt][e] = vt[u];
             }
         }
         __syncthreads();
