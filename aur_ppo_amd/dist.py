@@ -63,14 +63,29 @@ def allreduce_mean_(flat, world=None):
     return flat
 
 
-def allreduce_sum_(flat, world=None):
-    """In-place SUM over ranks; the caller folds the 1/W into its next kernel (``hip_ops.mlp_ppo_apply``)."""
+def allreduce_sum_(flat, world=None, force=False):
+    """In-place SUM over ranks; the caller folds the 1/W into its next kernel (``hip_ops.mlp_ppo_apply``).
+    ``force``: issue the collective even in a process group of one (rehearsal of the launch path)."""
     w = world_size() if world is None else world
-    if w > 1:
+    if w > 1 or (force and dist.is_available() and dist.is_initialized()):
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return flat
+
+
+def collectives_capturable():
+    """True when the default group's all-reduce can be recorded into a hipGraph: RCCL enqueues device work only;
+    gloo stages through host memory and cannot be captured.  A process without a group has nothing to capture."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return True
+    return dist.get_backend() == "nccl"
 
 
 def barrier():
     if world_size() > 1:
         dist.barrier()
+
+
+def shutdown():
+    """Tear the default group down (a clean exit: RCCL warns about leaked communicators otherwise)."""
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()

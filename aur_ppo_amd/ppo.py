@@ -147,7 +147,14 @@ class ppo:
         self._graph = None         # captured update (hipGraph), see update()
         self._graph_state = 0      # 0: next update runs eagerly (warm-up), 1: capture, 2: replay
         self._perm_static = None
-        self.use_graph = bool(params.get("hip_graph", True)) and self.device.type == "cuda" and self.world == 1
+        # one process per GPU: the update is captured too when the collective is capturable (RCCL is; gloo stages
+        # through the host and is not).  ``force_dp`` (test / rehearsal seam) takes the two-halves-around-the-all-reduce
+        # path with a world of one, so a one-GPU box can rehearse the captured RCCL launch.
+        self._dp = self.world > 1 or bool(params.get("force_dp", False))
+        self.use_graph = (bool(params.get("hip_graph", True)) and self.device.type == "cuda"
+                          and (not self._dp or D.collectives_capturable()))
+        self.graph_fallback = None  # why a captured update fell back to eager launches, if it did
+        self._perm_events = None   # bench.py: [(start, end)] HIP events around each update's K2 work on the side stream
         self._rec = None           # (B,4) per-sample record written by K1
         self._rec_of = None
         self._probe = None         # bench.py hangs HIP-event pairs around the gather launches here
@@ -229,9 +236,14 @@ class ppo:
             self._perm_stream = torch.cuda.Stream(device=self.device, priority=-1)   # latency-bound kernels: high priority
         self._perm_stream.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self._perm_stream):
+            if self._perm_events is not None:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record(self._perm_stream)
             self._perms = self.rng.shuffle_epochs(self.batch_size, self.num_update_epochs, out=out)
-            self._perm_ready = torch.cuda.Event()
+            self._perm_ready = torch.cuda.Event(enable_timing=self._perm_events is not None)
             self._perm_ready.record(self._perm_stream)
+            if self._perm_events is not None:
+                self._perm_events.append((e0, self._perm_ready))
 
     def _take_perms(self):
         if self._perms is None:
@@ -298,6 +310,7 @@ class ppo:
             self.buffer.states[step] = next_obs
             self.buffer.terminals[step] = next_done
             next_obs, next_done = self.rewards_to_go(step, next_obs, global_step, writer)
+        self._rollout_noise = None      # a stand-alone rewards_to_go() call draws fresh noise, as upstream does
         return next_obs, next_done, global_step
 
     def _rollout(self, next_obs, next_done, global_step, writer):
@@ -388,8 +401,18 @@ class ppo:
             # the packed body reads only static storage: the rollout buffer, self._rec, self._perm_static
             torch.cuda.synchronize(self.device)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._graph_steps = self._update_body(returns, advantages, self._perm_static, packed)
+            try:
+                # with a collective inside, other threads of the process group (its watchdog) may touch the runtime
+                # while this thread captures: keep the capture's error checking to this thread
+                with torch.cuda.graph(g, capture_error_mode="thread_local" if self._dp else "global"):
+                    self._graph_steps = self._update_body(returns, advantages, self._perm_static, packed)
+            except Exception as e:                      # every rank captures the same calls, so every rank lands here
+                if not self._dp:
+                    raise
+                self.graph_fallback = f"{type(e).__name__}: {e}"
+                self.use_graph = False
+                torch.cuda.synchronize(self.device)
+                return self._update_body(returns, advantages, perms, packed)
             self._graph = g
             self._graph_state = 2
         self._graph.replay()
@@ -406,11 +429,11 @@ class ppo:
         step = 0
         # single process, MLP policy, fused Adam over exactly the policy's bucket: K7 + clip + Adam chained, three
         # launches per minibatch (each call also prepares the statistics of the slice that follows it)
-        chain = (packed and self._mlp is not None and self.world == 1 and self._fused_adam
+        chain = (packed and self._mlp is not None and not self._dp and self._fused_adam
                  and self._bucket_is_policy and hasattr(ops, "mlp_ppo_minibatch"))
         # one process per GPU: the same chain in two halves around the gradient all-reduce (SUM; the 1/W rides in the
         # apply kernel), three launches + one collective per minibatch
-        chain_dp = (packed and self._mlp is not None and self.world > 1 and self._fused_adam
+        chain_dp = (packed and self._mlp is not None and self._dp and self._fused_adam
                     and self._bucket_is_policy and hasattr(ops, "mlp_ppo_grad"))
         k7_act, k7_rec = (None, self._rec64) if (packed and self._rec64 is not None) else (b_actions, self._rec)
         starts = list(range(0, B, M))
@@ -430,7 +453,7 @@ class ppo:
                     ops.mlp_ppo_grad(b_obs, k7_act, k7_rec, mb_inds, self.bucket.flat_param, self._mlp,
                                      self.bucket.flat_grad, self.clip_coeff, self.entropy_coeff, self.value_coeff,
                                      self.norm_adv, vmode, self._scalars[step], self._adam_t, chained=step > 0)
-                    D.allreduce_sum_(self.bucket.flat_grad, self.world)
+                    D.allreduce_sum_(self.bucket.flat_grad, self.world, force=True)
                     ops.mlp_ppo_apply(self.bucket.flat_param, self.bucket.flat_grad, self._adam_m, self._adam_v, self._mlp,
                                       self._lr_tensor, self._adam_t, self.max_grad_norm, g["betas"], g["eps"],
                                       self._norms[step:step + 1], grad_scale=1.0 / self.world, rec=k7_rec, next_idx=nxt)

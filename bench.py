@@ -8,9 +8,13 @@ Adam}.  Workload at --gpus 1 is the configuration the metric is quoted on (num_e
 obs 64, act 6, E=4, 4 minibatches, 2x64 tanh MLP); with N GPUs every rank keeps --envs-per-gpu
 envs (weak scaling, env-sharded, one gradient all-reduce per optimizer step).
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W]        (N > 1: spawns one child per GPU itself, before any GPU call)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
+
+The first (untimed) step is also the parity gate: at N=1 its advantages / returns / permutations / 16 x 9 loss scalars /
+final weights are compared with the oracle's reference-faithful CPU update of the same tensors (the update the
+cpu_baseline leg computes anyway) and the line carries "parity_checked".
 """
 from __future__ import annotations
 
@@ -42,11 +46,13 @@ def parse():
     ap.add_argument("--act-dim", type=int, default=6)
     ap.add_argument("--epochs", type=int, default=4)
     ap.add_argument("--minibatches", type=int, default=4)
-    ap.add_argument("--cpu-baseline-updates", type=int, default=4, help="timed CPU-oracle updates (0 = skip)")
+    ap.add_argument("--cpu-baseline-updates", type=int, default=3, help="timed CPU-oracle updates, median reported (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = usable cores, <=16)")
     ap.add_argument("--no-probe", action="store_true", help="do not time the gather kernel with HIP events")
     ap.add_argument("--no-graph", action="store_true", help="run the update eagerly instead of as a hipGraph")
     ap.add_argument("--no-fused-mlp", action="store_true", help="per-op path (K3 + torch nets + K5) instead of K7")
+    ap.add_argument("--force-dp", action="store_true", help="one rank, but the multi-GPU launch path: K7 grad -> RCCL "
+                    "all-reduce (group of one) -> apply; rehearses the captured collective on a one-GPU box")
     return ap.parse_args()
 
 
@@ -110,9 +116,46 @@ def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def cpu_baseline(args, data, init_sd, n_updates):
+def c_twins(args, data):
+    """the plain-C `_cpu` twins of the non-network kernels (oracle/aurppo_oracle.c: GAE scan, numpy-legacy
+    shuffle, gather, loss forward+backward), one thread, timed at the benchmarked sizes: what one update spends in them."""
+    from oracle import c_oracle as CO
+    T, N = args.num_steps, args.envs_per_gpu
+    B, M, E = T * N, T * N // args.minibatches, args.epochs
+    f = lambda k: data[k].numpy()
+    nv = np.zeros(N, np.float32)
+
+    def best(fn, n=3):
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)) * 1e3
+
+    gae_ms = best(lambda: CO.gae(f("rewards"), f("values"), f("terminals"), nv, f("next_done"), 0.99, 0.95))
+    mt = CO.MT(1)
+    idx = np.arange(B, dtype=np.int32)
+    shuf_ms = best(lambda: [mt.shuffle(idx) for _ in range(E)])
+    obs = f("states").reshape(B, -1)
+    rec = [f(k).reshape(-1) for k in ("log_probs", "rewards", "values", "values")]
+    mb = idx[:M].copy()
+    gat_ms = best(lambda: [CO.gather(mb, obs)] + [CO.gather(mb, r) for r in rec]) * E * args.minibatches
+    a = [r[mb] for r in rec]
+    loss_ms = best(lambda: CO.ppo_loss(a[0] + 0.01, a[0], a[1], a[2] + 0.1, a[2], a[3], a[1], 0.2, 0.0, 0.5, True, 1)) * E * args.minibatches
+    tot = gae_ms + shuf_ms + gat_ms + loss_ms
+    return {"what": "oracle/aurppo_oracle.c (gcc -O2, 1 thread), non-network stages of one update at the benchmarked size",
+            "gae_ms": round(gae_ms, 2), f"shuffle_{E}_epochs_ms": round(shuf_ms, 2),
+            f"gather_{E * args.minibatches}_minibatches_ms": round(gat_ms, 2),
+            f"loss_fwd_bwd_{E * args.minibatches}_minibatches_ms": round(loss_ms, 2), "total_ms_per_update": round(tot, 2),
+            "env_steps_per_s_non_network": round(B / (tot * 1e-3), 1)}
+
+
+def cpu_baseline(args, data, init_sd, n_updates, gpu_first):
     """The oracle's reference-faithful CPU update (same op sequence as src/ppo.py:125-142,213-269)
-    timed on this box's host cores -- a reported baseline, never the measured product path."""
+    timed on this box's host cores -- a reported baseline, never the measured product path.  BASELINE.md section 3
+    protocol: 1 warm-up + 3 timed updates, median.  The warm-up update starts from the same weights, data and shuffle
+    seed as the GPU's first step: ``gpu_first`` (that step's results) is checked against it -> (baseline, parity)."""
     from oracle import ppo_oracle as O
     cores = args.cpu_threads or usable_cores()
     torch.set_num_threads(cores)
@@ -124,30 +167,105 @@ def cpu_baseline(args, data, init_sd, n_updates):
     buf = {k: data[k] for k in ("states", "actions", "log_probs", "rewards", "terminals", "values")}
     rng = np.random.RandomState(1)
     t0 = time.perf_counter()
-    O.reference_update(net, opt, buf, data["next_obs"], data["next_done"], hp, rng, collect=False)   # warm-up
+    res = O.reference_update(net, opt, buf, data["next_obs"], data["next_done"], hp, rng, collect=True)   # warm-up
     warm = time.perf_counter() - t0
     log(f"cpu baseline warm-up update: {warm:.2f} s on {cores} threads")
+    parity = check_parity(gpu_first, res, net) if gpu_first is not None else None
     if warm > 20.0:          # keep the default run bounded: the warm-up itself is the sample
-        n_updates, dt, note = 1, warm, "1 full update (cold; longer than the 20 s budget so used as the sample)"
+        per, note = warm, "1 full update (cold; longer than the 20 s budget so used as the sample)"
     else:
-        t0 = time.perf_counter()
+        ts = []
         for _ in range(n_updates):
+            t0 = time.perf_counter()
             O.reference_update(net, opt, buf, data["next_obs"], data["next_done"], hp, rng, collect=False)
-        dt = time.perf_counter() - t0
-        note = f"1 warm-up + {n_updates} timed full updates"
-    return {"value": T * N * n_updates / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{note} (N={N}, T={T}, E={args.epochs}, {args.minibatches} minibatches) of "
-                      f"oracle.reference_update, torch CPU fp32, {cores} threads, {dt / n_updates:.2f} s/update"}
+            ts.append(time.perf_counter() - t0)
+        per = float(np.median(ts))
+        note = f"1 warm-up + {n_updates} timed full updates, median"
+    out = {"value": T * N / per, "unit": "env-steps/s", "cores": cores, "kind": "port",
+           "sample": f"{note} (N={N}, T={T}, E={args.epochs}, {args.minibatches} minibatches) of "
+                     f"oracle.reference_update, torch CPU fp32, {cores} threads, {per:.2f} s/update"}
+    try:
+        out["c_twins"] = c_twins(args, data)
+    except Exception as e:      # the twins are an extra figure; never lose the line over them
+        out["c_twins"] = {"error": f"{type(e).__name__}: {e}"}
+    return out, parity
+
+
+def check_parity(gpu, res, net):
+    """First GPU step vs the oracle's update of the same tensors (tolerances of tests/test_parity_fullsize.py).
+    Returns {"ok": bool, ...max deviations...}."""
+    out = {}
+    try:
+        out["perms_bit_exact"] = bool(all(np.array_equal(gpu["perms"][e], res["perms"][e]) for e in range(len(res["perms"]))))
+        out["adv_max_abs_err"] = float(np.abs(gpu["adv"] - res["advantages"].numpy()).max())
+        out["ret_max_abs_err"] = float(np.abs(gpu["ret"] - res["returns"].numpy()).max())
+        cols = [0, 1, 2, 3, 4, 5, 7, 8]
+        g, r = gpu["scalars"][:, cols], res["scalars"][:, cols]
+        out["scalars_max_excess"] = float((np.abs(g - r) - (1e-5 + 1e-4 * np.abs(r))).max())     # <= 0 passes
+        out["clipfrac_max_abs_err"] = float(np.abs(gpu["scalars"][:, 6] - res["scalars"][:, 6]).max())
+        w_ex = []
+        for k, v in net.state_dict().items():
+            a, b = gpu["weights"][k], v.numpy()
+            w_ex.append(float((np.abs(a - b) - (2e-6 + 1e-4 * np.abs(b))).max()))
+        out["weights_max_excess"] = max(w_ex)
+        M = gpu["minibatch"]
+        out["ok"] = bool(out["perms_bit_exact"] and out["adv_max_abs_err"] <= 1e-5 and out["ret_max_abs_err"] <= 1e-5
+                         and gpu["scalars"].shape == res["scalars"].shape and out["scalars_max_excess"] <= 0
+                         and out["clipfrac_max_abs_err"] <= 1.5 / M and out["weights_max_excess"] <= 0)
+    except Exception as e:
+        out["ok"] = False
+        out["error"] = f"{type(e).__name__}: {e}"
+    return out
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` as typed: one child per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in its
+    environment), started BEFORE this process makes any GPU call -- a process that has touched the GPU is never
+    re-exec'ed.  Rank 0 prints the JSON line; this parent only waits and relays the exit code."""
+    import socket
+    import subprocess
+    n = args.gpus
+    if os.environ.get("AURPPO_BENCH_REHEARSE") != "1" and torch.cuda.device_count() < n:     # device_count() creates no context
+        sys.exit(f"bench.py: --gpus {n} but {torch.cuda.device_count()} GPU(s) visible")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in live:          # one rank failed: the others would wait in a collective for ever
+                    q.terminate()
+    sys.exit(rc)
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     from aur_ppo_amd import dist as D
     # AURPPO_BENCH_REHEARSE=1: every rank on cuda:0 over gloo -- a rehearsal of the N > 1 code path on a one-GPU box
     # (its timings mean nothing); the driver's runs use one device per rank over RCCL
     rehearse = os.environ.get("AURPPO_BENCH_REHEARSE") == "1"
+    if args.force_dp and args.gpus == 1 and "WORLD_SIZE" not in os.environ:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29533"))
+        torch.cuda.set_device(0)
+        torch.distributed.init_process_group("nccl", rank=0, world_size=1)      # RCCL communicator of one
     rank, local_rank, world = D.init_from_env(backend="gloo" if rehearse else None)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if rehearse:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -157,6 +275,7 @@ def main():
     hp = hyper(args, world)
     hp["device"] = dev
     hp["fused_mlp"] = not args.no_fused_mlp
+    hp["force_dp"] = args.force_dp
     agent = ppo(hp)
     T, N, Dm, A = args.num_steps, agent.num_envs, args.obs_dim, args.act_dim
     data = synth_buffers(T, N, Dm, A, 1234 + rank)
@@ -190,21 +309,37 @@ def main():
             else:
                 agent.probe_gather(probe)
 
-    log(f"rank {rank}/{world}: setup done, {args.warmup} warm-up steps")
+    log(f"rank {rank}/{world}: setup done; parity step, then {args.warmup} warm-up steps")
+    # step 0 (untimed, eager): the update the oracle's first CPU update is compared with
+    returns, advantages = agent.advantages(next_obs, next_done)
+    n0 = agent.update(returns, advantages)
+    torch.cuda.synchronize()
+    gpu_first = None
+    if rank == 0 and world == 1 and not args.force_dp:
+        gpu_first = dict(adv=advantages.cpu().numpy(), ret=returns.cpu().numpy(), perms=agent._last_perms.cpu().numpy(),
+                         scalars=agent._scalars[:n0].cpu().numpy().astype(np.float64), minibatch=agent.minibatch_size,
+                         weights={k: v.detach().cpu().numpy().copy() for k, v in agent.policy.state_dict().items()})
     for _ in range(args.warmup):
         one_step()
     torch.cuda.synchronize()
     log("warm-up done, timing")
     probe.on = True
+    side = []
+    agent._perm_events = [] if agent._perm_stream is not None else None
     D.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
+        if agent._perm_events is not None:          # when did the main stream finish this update?
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            side.append(e)
     torch.cuda.synchronize()
     D.barrier()
     dt = time.perf_counter() - t0
     probe.on = False
+    perm_events, agent._perm_events = agent._perm_events, None
     log(f"timed region: {dt:.3f} s for {args.steps} steps")
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -213,6 +348,7 @@ def main():
     sc = agent._scalars.cpu().numpy()
     assert np.isfinite(sc).all(), "non-finite loss scalars in the timed region"
     if rank != 0:
+        D.shutdown()
         return
     env_steps = world * N * T * args.steps
     M = agent.minibatch_size
@@ -227,6 +363,27 @@ def main():
         except Exception:
             return None
 
+    B = N * T
+    bytes_8d = (20 + args.epochs * (8 * Dm + 8 * A + 84)) * B            # 2 596 B/env-step at D=64, A=6, E=4
+    ms_step = dt / args.steps * 1e3
+    hbm_8d = {"bytes_per_step": bytes_8d, "achieved_GBs": round(bytes_8d / (ms_step * 1e-3) / 1e9, 1), "peak_GBs": HBM_PEAK_GBS,
+              "frac": round(bytes_8d / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+              "note": "SURVEY 8d's algorithmic HBM bytes of GAE + E epochs of shuffle/gather/loss (policy nets excluded) over "
+                      "the whole measured step.  north_star's 40 % of HBM presumes the nets run elsewhere; with the fp32 "
+                      "actor/critic fused into the step (K7) the floor is 16 x 11.09 GFLOP / 157.3 TFLOP/s = 1.13 ms per "
+                      "update, i.e. <= 15 % of this HBM figure is attainable at all: the step is MFMA-bound, see the main view"}
+    side_stream = None
+    if perm_events and len(perm_events) >= 3 and len(side) >= 3:
+        # K2 for update u+1 is enqueued at the start of update u: busy = its own start -> end on the side stream (the
+        # shortest period the shuffle pipeline could sustain); slack = how long before the main stream finished update u
+        # the permutations of u+1 were ready
+        k = min(len(perm_events), len(side))
+        busy = [a.elapsed_time(b) for a, b in perm_events[:k]]
+        slack = [pe[1].elapsed_time(me) for pe, me in zip(perm_events[:k], side[:k])]
+        side_stream = {"k2_period_ms": round(float(np.median(busy)), 4), "slack_ms": round(float(np.median(slack)), 4),
+                       "main_period_ms": round(ms_step, 4),
+                       "how": "HIP events on the shuffle side stream (start/end of each update's E shuffles) and on the main "
+                              "stream (end of each update) in this same timed region; medians"}
     roofline = None
     if mlp_events:
         from aur_ppo_amd import hip_ops as H
@@ -250,6 +407,14 @@ def main():
                     "bytes_per_launch": gather_bytes, "avg_launch_us": round(g_ms * 1e3, 2),
                     "launches_timed": len(probe.pairs),
                     "how": "HIP-event pairs around one stand-alone launch every 4th step of the update's own gather"}
+    if roofline is not None:
+        roofline["hbm_8d"] = hbm_8d
+        roofline["side_stream"] = side_stream
+    launch = "hipGraph" if agent._graph is not None else "eager"
+    if agent.graph_fallback:
+        launch += f" (capture failed: {agent.graph_fallback[:120]})"
+    elif agent._graph is None and world > 1 and not D.collectives_capturable():
+        launch += " (gloo rehearsal: a host-staged collective cannot be captured; RCCL runs captured)"
     out = {"metric": "env-steps/sec through GAE+PPO-update at num_envs=4096,T=128; 1/2/4/8 GPU",
            "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -257,15 +422,22 @@ def main():
            "config": {"workload": f"synthetic continuous obs_dim={Dm} act_dim={A}, num_envs={N}/GPU x {world} GPU, "
                                   f"T={T}, E={args.epochs}, {args.minibatches} minibatches/epoch (M={M}), 2x64 tanh "
                                   "MLP actor+critic, Adam, random-init weights",
-                      "global_num_envs": N * world, "num_steps": T, "parallelism": f"env-shard dp{world}",
-                      "update_launch": "hipGraph" if agent._graph is not None else "eager",
+                      "global_num_envs": N * world, "num_steps": T,
+                      "parallelism": f"env-shard dp{world}" + (" (one rank through the RCCL launch path)" if args.force_dp else ""),
+                      "update_launch": launch,
                       "minibatch_step": "K7 fused MLP step" if agent._mlp is not None else "K3 + torch nets + K5"},
            "roofline": roofline}
+    parity = None
     if world == 1 and args.cpu_baseline_updates > 0:
-        out["cpu_baseline"] = cpu_baseline(args, data, init_sd, args.cpu_baseline_updates)
+        out["cpu_baseline"], parity = cpu_baseline(args, data, init_sd, args.cpu_baseline_updates, gpu_first)
     else:
         out["cpu_baseline"] = None
+    out["parity_checked"] = bool(parity["ok"]) if parity is not None else False
+    out["parity"] = parity if parity is not None else "not run (needs the N=1 cpu_baseline leg)"
     print(json.dumps(out), flush=True)
+    D.shutdown()
+    if parity is not None and not parity["ok"]:
+        sys.exit("bench.py: the GPU's first update does NOT match the oracle's -- see \"parity\" in the line above")
 
 
 if __name__ == "__main__":

@@ -113,3 +113,68 @@ def test_two_ranks_on_the_hip_path(tmp_path):
                     a._clip_and_step(a._norms[:1])
     torch.cuda.synchronize()
     torch.testing.assert_close(a0.bucket.flat_param.cpu(), r0["p1"], rtol=1e-6, atol=1e-7)
+
+
+# ---------------------------------------------------------------------------------- RCCL: the captured collective
+def _rccl_worker(rank, world, port, out_dir, force_dp, use_graph):
+    """One process per device over backend "nccl" (= RCCL).  world == 1 + force_dp: the multi-GPU launch path (K7 grad ->
+    all-reduce -> apply) through a communicator of one -- what a one-GPU box can rehearse of the captured collective."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    torch.distributed.init_process_group("nccl", rank=rank, world_size=world)
+    from aur_ppo_amd.ppo import ppo
+    torch.manual_seed(50 + rank)
+    agent = ppo(_params(64, device=torch.device("cuda", rank), force_dp=force_dp, hip_graph=use_graph,
+                        total_timesteps=16 * 64 * 4))
+    per = 64 // world
+    assert agent._dp and agent.num_envs == per and agent.use_graph == use_graph
+    p0 = agent.bucket.flat_param.clone().cpu()
+    sc = _run(agent, _rollout(16, 64), agent.env_lo, agent.env_lo + per, updates=4)
+    torch.save(dict(p0=p0, p1=agent.bucket.flat_param.clone().cpu(), sc=sc, norms=agent._norms.clone().cpu(),
+                    captured=agent._graph is not None, fallback=agent.graph_fallback),
+               os.path.join(out_dir, f"r{rank}_{int(use_graph)}.pt"))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_one_rank_rccl_update_is_captured_as_hipgraph(tmp_path):
+    """The W > 1 update (16 x {aurppo_mlp_ppo_grad_f32, RCCL all-reduce, aurppo_mlp_ppo_apply_f32}) recorded into ONE
+    hipGraph and replayed: eager / capture / replay / replay must end where four eager updates end, and where the
+    single-process chained path ends."""
+    for use_graph in (True, False):
+        mp.start_processes(_rccl_worker, args=(1, _free_port(), str(tmp_path), True, use_graph), nprocs=1, join=True,
+                           start_method="spawn")
+    g, e = torch.load(tmp_path / "r0_1.pt"), torch.load(tmp_path / "r0_0.pt")
+    assert g["captured"], f"the update with the collective inside was not captured: {g['fallback']}"
+    assert not e["captured"]
+    torch.testing.assert_close(g["sc"], e["sc"], rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(g["p1"], e["p1"], rtol=1e-6, atol=1e-8)
+    # the plain single-process trainer (chained K7 -> reduce -> clip+Adam) from the same start
+    from aur_ppo_amd.ppo import ppo
+    a = ppo(_params(64, total_timesteps=16 * 64 * 4, hip_graph=False))
+    with torch.no_grad():
+        a.bucket.flat_param.copy_(g["p0"].cuda())
+    sc = _run(a, _rollout(16, 64), 0, 64, updates=4)
+    torch.testing.assert_close(g["sc"], sc, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(g["p1"], a.bucket.flat_param.cpu(), rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")
+def test_two_ranks_over_rccl_captured(tmp_path):
+    """What test_two_ranks_on_the_hip_path asserts, over backend "nccl" on two devices, with the update captured."""
+    mp.start_processes(_rccl_worker, args=(2, _free_port(), str(tmp_path), False, True), nprocs=2, join=True,
+                       start_method="spawn")
+    r0, r1 = (torch.load(tmp_path / f"r{k}_1.pt") for k in range(2))
+    assert r0["captured"] and r1["captured"], (r0["fallback"], r1["fallback"])
+    assert torch.equal(r0["p0"], r1["p0"])
+    assert torch.equal(r0["p1"], r1["p1"])
+    assert torch.equal(r0["norms"], r1["norms"])
+    assert not torch.equal(r0["sc"], r1["sc"])
+    mp.start_processes(_rccl_worker, args=(2, _free_port(), str(tmp_path), False, False), nprocs=2, join=True,
+                       start_method="spawn")
+    e0 = torch.load(tmp_path / "r0_0.pt")
+    assert not e0["captured"]
+    torch.testing.assert_close(r0["p1"], e0["p1"], rtol=1e-6, atol=1e-8)
+    torch.testing.assert_close(r0["sc"], e0["sc"], rtol=1e-6, atol=1e-7)
