@@ -7,9 +7,10 @@
 //
 // Design (gfx950).  The swap chain is n dependent memory transactions if done literally, so it is
 // split into the part that is inherently a stream and the part that is not:
-//   1a. k_mt_fill -- one 256-thread workgroup runs the twist only: 624-word blocks ping-pong between
-//      two LDS buffers (3 barriers per block, the recurrence's three dependency phases) and the
-//      tempered words stream out to a word buffer in HBM.
+//   1a. k_mt_fill -- one workgroup runs the twist only, as 227-word phases of the recurrence
+//      x[m] = x[m-227] ^ mix(x[m-624], x[m-623]): a lane owns one offset of every phase (x[m-227] is its own previous
+//      output, a register), two phases share a barrier, and four helper waves temper and store the words to a ring in
+//      HBM one barrier behind the four that twist.  It runs one shuffle ahead of its consumer on the handle's own stream.
 //   1b. k_fy_accept -- one 1024-thread workgroup turns 8192 draws per step into accept/reject
 //      decisions.  Whether draw p is accepted depends on the index i it is tried against, i.e. on how
 //      many earlier draws were accepted -- a triangular system.  Each thread resolves its own 8
@@ -19,7 +20,7 @@
 //      guess, and the first guess uses the acceptance rate of the previous step).  ~90 sequential
 //      steps per 524288-element shuffle instead of ~1170.  Output: the swap targets j[1..n).
 //   2. k_fy_link / k_fy_resolve -- given j, the final content of every position is found in
-//      parallel with no swaps at all.  Step s writes old x[s] into position j_s, so "what sits in
+//      parallel with no swaps at all (link behind the accept; resolve on the fill stream, beside the NEXT accept).  Step s writes old x[s] into position j_s, so "what sits in
 //      position q just before step t" is "what step min{s>t : j_s=q} put there", recursively.
 //      Linked lists per target (atomicExch) give those predecessor sets; chains are O(log n) and
 //      almost always empty, so each element resolves with a handful of L2-resident loads.
@@ -35,15 +36,20 @@ struct aurppo_rng {
     uint32_t* d_last;    // [624] untempered form of the last block written to the ring
     uint32_t* d_ring;    // ring of tempered draws; stream word g lives at d_ring[g % ring_cap]
     long long* d_pos;    // [0] words written (stream offset), [1] words consumed (read cursor), [2] sticky error
-    int32_t* d_j;        // swap targets
-    int32_t* d_head;     // list head per target position
-    int32_t* d_next;     // list link per step
+    // Shuffle e's accept + link run on the caller's stream while shuffle e-1's resolve runs on the fill stream, so the
+    // per-shuffle scratch is multi-buffered: swap targets and list links by parity, list heads three deep (the accept
+    // of shuffle e clears the heads shuffle e+1 will link into while shuffle e-1's resolve may still read its own).
+    int32_t* d_j[2];     // swap targets
+    int32_t* d_head[3];  // list head per target position
+    int32_t* d_next[2];  // list link per step
+    int head_clean[3];   // how many leading entries of d_head[k] are known to be -1 when its next user starts
     int32_t* d_tmp;      // out-of-place result for the in-place API
     int32_t* d_meta;     // accept scratch
     int max_n;
+    size_t head_cap;     // entries per d_head buffer (max_n rounded up to whole clear chunks)
     size_t ring_cap;     // words, a multiple of 624
-    hipStream_t fill_stream;   // the twist runs one shuffle ahead of its consumer on this stream
-    hipEvent_t ev_fill[2], ev_acc[2], ev_sync;
+    hipStream_t fill_stream;   // the twist runs one shuffle ahead of its consumer on this stream; resolves follow it there
+    hipEvent_t ev_fill[2], ev_acc[2], ev_link[2], ev_res, ev_sync;
     long seq;            // shuffles issued since the last (re)seed
     double primed_need;  // words-per-shuffle the look-ahead fill was sized for (0: nothing in flight)
 };
@@ -102,12 +108,23 @@ constexpr int kRingMirror = 64;
 // left on the critical path of a phase is one XOR, one LDS write and the barrier that publishes it -- and two phases
 // share one barrier (below); tempering and the (coalesced) ring store hang off the side.  The block formulation
 // this replaces needed three barrier-separated passes with an LDS round trip each per 624 words.
-constexpr int kFillWin = 2048;   // LDS window over the untempered stream (power of two, >= 624 + 2 * 227)
+constexpr int kFillWin = 2048;   // LDS window over the untempered stream (power of two, >= 624 + 2 * 454)
+constexpr int kFillProd = 256;   // waves 0-3: the twist (227 lanes carry a word each)
+constexpr int kFillAll = 768;    // waves 4-11: tempering + ring stores of the pair produced one barrier earlier
+constexpr int kPair = 2 * kMtD;  // words per barrier interval
 
-__global__ __launch_bounds__(kFillThreads) void k_mt_fill(uint32_t* __restrict__ last, uint32_t* __restrict__ ring,
-                                                          long long ring_cap, long long* __restrict__ posv,
-                                                          long long target, int nblk_max, int cur_slot) {
-    __shared__ uint32_t win[kFillWin];
+// Roles.  What a barrier interval must contain is: LDS reads of the mix inputs -> two XORs -> LDS writes -> barrier.
+// Everything else a word needs (tempering: 13 VALU ops, the ring slot arithmetic, the global store and the mirrored
+// head) is off that chain: the producer waves hand the untempered pair to four more waves of the same workgroup
+// through the LDS window they write anyway, and those temper and store it during the NEXT interval, in the issue
+// slots the producers leave free while they wait for LDS.  (First version: every lane tempered and stored its own
+// words between the LDS writes and the barrier -- ~95 instructions per wave on the chain, 750 cycles per interval.
+// With four helper waves taking two words each, one after the other, the helpers were the last to reach the barrier:
+// eight of them take one word each.)
+__global__ __launch_bounds__(kFillAll) void k_mt_fill(uint32_t* __restrict__ last, uint32_t* __restrict__ ring,
+                                                      long long ring_cap, long long* __restrict__ posv,
+                                                      long long target, int nblk_max, int cur_slot) {
+    __shared__ uint32_t win[kFillWin + kWave];      // + a dummy slot per lane for writes that are masked off
     const int tid = threadIdx.x;
     const long long S = posv[0];
     // Cursor as of the end of a SPECIFIC earlier shuffle (slot 4/5 by parity; slot 1 = live value for the
@@ -121,46 +138,52 @@ __global__ __launch_bounds__(kFillThreads) void k_mt_fill(uint32_t* __restrict__
     // local numbering: x[0 .. 624) is the last block of the previous call, new words are x[624 ..  624 + total)
     const int total = nblk * kMtN;
     const int m_end = kMtN + total;
-    for (int k = tid; k < kMtN; k += kFillThreads) win[k] = last[k];
+    const int cap = (int)ring_cap;
+    const int at0 = (int)(S % ring_cap);                           // ring slot of x[624]
+    for (int k = tid; k < kMtN; k += kFillAll) win[k] = last[k];
     __syncthreads();
-    const bool lane_on = tid < kMtD;
-    int m = kMtN + tid;                                         // my word of phase 0
-    uint32_t prev = lane_on ? win[kMtM + tid] : 0u;             // x[m - 227]
-    long long at = S % ring_cap + tid;                          // ring slot of x[m]
-    if (at >= ring_cap) at -= ring_cap;
-    // Two phases per barrier.  Phase p reads words written in phases p-3 and p-2, so the two phases of a pair (2g, 2g+1)
-    // only need what was complete at the barrier that ended pair g-1 -- a barrier costs about as much as the rest of a
-    // phase (rocprof: ~420 cycles per phase whatever the arithmetic in it), so pairing halves what dominates.  Three
-    // in a row would need phase 3g's words inside the same group.
-    const int nphase = (total + kMtD - 1) / kMtD;
-    for (int p = 0; p < nphase; p += 2) {
-        // inputs of both phases, all written before the last barrier: x[m-624], x[m-623] and the same 227 further on
-        const uint32_t a0 = win[(m - kMtN) & (kFillWin - 1)], b0 = win[(m - kMtN + 1) & (kFillWin - 1)];
-        const uint32_t a1 = win[(m - kMtM) & (kFillWin - 1)], b1 = win[(m - kMtM + 1) & (kFillWin - 1)];
-        const uint32_t n0 = prev ^ mt_mix(a0, b0);          // x[m]       = x[m - 227] ^ ...
-        const uint32_t n1 = n0 ^ mt_mix(a1, b1);            // x[m + 227] = x[m]       ^ ...
-        prev = n1;
-        const bool on0 = lane_on && m < m_end, on1 = lane_on && m + kMtD < m_end;
-        if (on0) {
-            win[m & (kFillWin - 1)] = n0;
-            const uint32_t t = mt_temper(n0);
-            ring[at] = t;
-            if (at < kRingMirror) ring[ring_cap + at] = t;
+    const int npair = (total + kPair - 1) / kPair;
+    const bool producer = tid < kFillProd;                         // wave-uniform
+    if (producer) {
+        const bool lane_on = tid < kMtD;
+        const int dummy = kFillWin + (tid & (kWave - 1));
+        int m = kMtN + tid;                                         // my word of the pair's first phase
+        uint32_t prev = lane_on ? win[kMtM + tid] : 0u;             // x[m - 227]
+        // Two phases per barrier: phase p reads words written in phases p-3 and p-2, so both phases of a pair only need
+        // what was complete at the previous barrier; x[m - 227] is this lane's own previous output -- a register.
+        uint32_t a0 = win[(m - kMtN) & (kFillWin - 1)], b0 = win[(m - kMtN + 1) & (kFillWin - 1)];
+        uint32_t a1 = win[(m - kMtM) & (kFillWin - 1)], b1 = win[(m - kMtM + 1) & (kFillWin - 1)];
+        for (int pr = 0; pr < npair; ++pr) {
+            const uint32_t n0 = prev ^ mt_mix(a0, b0);          // x[m]       = x[m - 227] ^ ...
+            const uint32_t n1 = n0 ^ mt_mix(a1, b1);            // x[m + 227] = x[m]       ^ ...
+            prev = n1;
+            win[(lane_on && m < m_end) ? (m & (kFillWin - 1)) : dummy] = n0;
+            win[(lane_on && m + kMtD < m_end) ? ((m + kMtD) & (kFillWin - 1)) : dummy] = n1;
+            m += kPair;
+            __syncthreads();
+            a0 = win[(m - kMtN) & (kFillWin - 1)];
+            b0 = win[(m - kMtN + 1) & (kFillWin - 1)];
+            a1 = win[(m - kMtM) & (kFillWin - 1)];
+            b1 = win[(m - kMtM + 1) & (kFillWin - 1)];
         }
-        long long at1 = at + kMtD;
-        if (at1 >= ring_cap) at1 -= ring_cap;
-        if (on1) {
-            win[(m + kMtD) & (kFillWin - 1)] = n1;
-            const uint32_t t = mt_temper(n1);
-            ring[at1] = t;
-            if (at1 < kRingMirror) ring[ring_cap + at1] = t;
+    } else {
+        const int c = tid - kFillProd;                              // word c of a pair (lanes 454.. idle)
+        for (int pr = 0; pr <= npair; ++pr) {
+            if (pr > 0) {
+                const int w = kMtN + (pr - 1) * kPair + c;          // in the pair finished one barrier ago
+                const uint32_t t = mt_temper(win[w & (kFillWin - 1)]);
+                int at = at0 + (w - kMtN);
+                at -= at >= cap ? cap : 0;
+                if (c < kPair && w < m_end) {
+                    ring[at] = t;
+                    if (at < kRingMirror) ring[cap + at] = t;
+                }
+            }
+            if (pr < npair) __syncthreads();
         }
-        m += 2 * kMtD;
-        at = at1 + kMtD;
-        if (at >= ring_cap) at -= ring_cap;
-        __syncthreads();
     }
-    for (int k = tid; k < kMtN; k += kFillThreads) last[k] = win[(m_end - kMtN + k) & (kFillWin - 1)];
+    __syncthreads();
+    for (int k = tid; k < kMtN; k += kFillAll) last[k] = win[(m_end - kMtN + k) & (kFillWin - 1)];
     if (tid == 0) posv[0] = S + total;
 }
 
@@ -456,11 +479,20 @@ __global__ __launch_bounds__(kAccThreads) void k_fy_accept(const uint32_t* __res
     }
 }
 
+// Side job: clr[0 .. clr_n) = -1 (clr_n a multiple of 4, 16-B aligned) -- the list heads the NEXT shuffle links into.
+// (It was a memset between accept and link: 5 us of work that had to find a free CU beside K7, ~100 us in-situ; as
+// stores inside the single-workgroup accept kernel it cost that kernel 20-40 us.)
 __global__ void k_fy_link(const int32_t* __restrict__ j, int32_t* __restrict__ head, int32_t* __restrict__ next,
-                          int n) {
+                          int n, int32_t* __restrict__ clr, int clr_n) {
     // grid-stride, four positions per pass: their swaps are in flight together (a memory-side atomic takes ~1 us)
     constexpr int kB = 4;
     const int stride = gridDim.x * blockDim.x;
+    {
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        const i32x4 m1 = {-1, -1, -1, -1};
+        i32x4* dst = reinterpret_cast<i32x4*>(clr);
+        for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < clr_n / 4; q += stride) dst[q] = m1;
+    }
     for (int s0 = blockIdx.x * blockDim.x + threadIdx.x; s0 < n; s0 += kB * stride) {
         int js[kB], old[kB];
 #pragma unroll
@@ -565,12 +597,14 @@ static int enqueue_fill(aurppo_rng* rng, double need, hipStream_t after, int slo
     AURPPO_HIP_TRY(hipStreamWaitEvent(rng->fill_stream, rng->ev_sync, 0));
     const int nblk_max = (int)(2.0 * need / kMtN) + 2;
     AURPPO_HIP_TRY(own_cu_setup());
-    hipLaunchKernelGGL(k_mt_fill, dim3(1), dim3(kFillThreads), kOwnCuLds, rng->fill_stream, rng->d_last, rng->d_ring,
+    hipLaunchKernelGGL(k_mt_fill, dim3(1), dim3(kFillAll), kOwnCuLds, rng->fill_stream, rng->d_last, rng->d_ring,
                        (long long)rng->ring_cap, rng->d_pos, (long long)(2.0 * need), nblk_max, cur_slot);
     AURPPO_LAUNCH_CHECK("k_mt_fill");
     AURPPO_HIP_TRY(hipEventRecord(rng->ev_fill[slot], rng->fill_stream));
     return AURPPO_OK;
 }
+
+constexpr int kClrChunk = 4096;         // head buffers are sized and cleared in whole chunks
 
 int permute_once(aurppo_rng* rng, const int32_t* in, int32_t* out, int n, hipStream_t s) {
     const double need = need_words(n);
@@ -579,6 +613,7 @@ int permute_once(aurppo_rng* rng, const int32_t* in, int32_t* out, int n, hipStr
         return AURPPO_ESHAPE;
     }
     const int slot = (int)(rng->seq & 1);
+    const int h = (int)(rng->seq % 3), hn = (int)((rng->seq + 1) % 3);
     if (rng->primed_need < need) {
         // nothing (or too little) in flight for this size: produce this shuffle's draws now
         // (ordered after everything on `s`, so the live cursor in slot 1 is final)
@@ -588,23 +623,20 @@ int permute_once(aurppo_rng* rng, const int32_t* in, int32_t* out, int n, hipStr
     }
     AURPPO_HIP_TRY(hipStreamWaitEvent(s, rng->ev_fill[slot], 0));
     AURPPO_HIP_TRY(own_cu_setup());
-    hipLaunchKernelGGL((k_fy_accept<1024, 8>), dim3(1), dim3(1024), kOwnCuLds, s, rng->d_ring, (long long)rng->ring_cap,
-                       rng->d_j, n, rng->d_pos, 4 + slot);
-    AURPPO_LAUNCH_CHECK("k_fy_accept");
-    // Look-ahead: the NEXT shuffle's draws (assumed the same size) are twisted on the fill stream while
-    // this shuffle's accept / link / resolve run here.  It is ordered after the PREVIOUS accept (ev_acc of
-    // the other slot), so the cursor it reads is at most one shuffle stale -- what the 2*need target covers.
-    if (rng->seq > 0) AURPPO_HIP_TRY(hipStreamWaitEvent(rng->fill_stream, rng->ev_acc[slot ^ 1], 0));
-    {
-        const int nblk_max = (int)(2.0 * need / kMtN) + 2;
-        hipLaunchKernelGGL(k_mt_fill, dim3(1), dim3(kFillThreads), kOwnCuLds, rng->fill_stream, rng->d_last, rng->d_ring,
-                           (long long)rng->ring_cap, rng->d_pos, (long long)(2.0 * need), nblk_max,
-                           rng->seq > 0 ? 4 + (slot ^ 1) : 1);   // cursor after the PREVIOUS shuffle (done: waited above)
-        AURPPO_LAUNCH_CHECK("k_mt_fill");
-        AURPPO_HIP_TRY(hipEventRecord(rng->ev_fill[slot ^ 1], rng->fill_stream));
+    if (rng->head_clean[h] < n) {
+        // first shuffle after a (re)start, or a larger n than the previous call prepared: clear here (rare path)
+        AURPPO_HIP_TRY(hipMemsetAsync(rng->d_head[h], 0xff, sizeof(int32_t) * (size_t)n, s));
+        rng->head_clean[h] = n;
     }
+    hipLaunchKernelGGL((k_fy_accept<1024, 8>), dim3(1), dim3(1024), kOwnCuLds, s, rng->d_ring, (long long)rng->ring_cap,
+                       rng->d_j[slot], n, rng->d_pos, 4 + slot);
+    AURPPO_LAUNCH_CHECK("k_fy_accept");
     AURPPO_HIP_TRY(hipEventRecord(rng->ev_acc[slot], s));
-    AURPPO_HIP_TRY(hipMemsetAsync(rng->d_head, 0xff, sizeof(int32_t) * (size_t)n, s));
+    // the link kernel also clears the heads of the NEXT shuffle (same n assumed; a larger one takes the path above).
+    // Their last reader, the resolve of shuffle seq-2, precedes the fill this shuffle's accept waited for.
+    const int clr_n = (int)(((size_t)n + kClrChunk - 1) / kClrChunk * kClrChunk);
+    rng->head_clean[hn] = n;
+    rng->head_clean[h] = 0;      // about to be linked into
     const int grid = (n + 255) / 256;
     // k_fy_link strides over the positions with a bounded grid.  It runs beside K7, whose workgroups fill the register
     // file of every CU but the spare ones, so a few dozen workgroups are all that is ever resident; one workgroup per
@@ -615,12 +647,36 @@ int permute_once(aurppo_rng* rng, const int32_t* in, int32_t* out, int n, hipStr
         const char* e = getenv("AURPPO_K2_LINK_WGS");
         link_wgs = e && *e ? atoi(e) : 48;
     }
-    hipLaunchKernelGGL(k_fy_link, dim3(link_wgs > 0 && link_wgs < grid ? link_wgs : grid), dim3(256), 0, s, rng->d_j, rng->d_head,
-                       rng->d_next, n);
+    hipLaunchKernelGGL(k_fy_link, dim3(link_wgs > 0 && link_wgs < grid ? link_wgs : grid), dim3(256), 0, s, rng->d_j[slot],
+                       rng->d_head[h], rng->d_next[slot], n, rng->d_head[hn], clr_n);
     AURPPO_LAUNCH_CHECK("k_fy_link");
-    hipLaunchKernelGGL(k_fy_resolve, dim3(grid), dim3(256), 0, s, rng->d_j, rng->d_head, rng->d_next, in, out, n);
+    AURPPO_HIP_TRY(hipEventRecord(rng->ev_link[slot], s));
+    // Fill stream, in this order: the NEXT shuffle's draws (assumed the same size; ordered after the PREVIOUS accept,
+    // ev_acc of the other slot, so the cursor it reads is at most one shuffle stale -- what the 2*need target
+    // covers), then THIS shuffle's resolve.  The caller's stream is then free for the next accept while the resolve
+    // runs: per shuffle the two streams carry {accept, link} and {fill, resolve} instead of {accept, memset, link,
+    // resolve} and {fill}.
+    if (rng->seq > 0) AURPPO_HIP_TRY(hipStreamWaitEvent(rng->fill_stream, rng->ev_acc[slot ^ 1], 0));
+    {
+        const int nblk_max = (int)(2.0 * need / kMtN) + 2;
+        hipLaunchKernelGGL(k_mt_fill, dim3(1), dim3(kFillAll), kOwnCuLds, rng->fill_stream, rng->d_last, rng->d_ring,
+                           (long long)rng->ring_cap, rng->d_pos, (long long)(2.0 * need), nblk_max,
+                           rng->seq > 0 ? 4 + (slot ^ 1) : 1);   // cursor after the PREVIOUS shuffle (done: waited above)
+        AURPPO_LAUNCH_CHECK("k_mt_fill");
+        AURPPO_HIP_TRY(hipEventRecord(rng->ev_fill[slot ^ 1], rng->fill_stream));
+    }
+    AURPPO_HIP_TRY(hipStreamWaitEvent(rng->fill_stream, rng->ev_link[slot], 0));
+    hipLaunchKernelGGL(k_fy_resolve, dim3(grid), dim3(256), 0, rng->fill_stream, rng->d_j[slot], rng->d_head[h],
+                       rng->d_next[slot], in, out, n);
     AURPPO_LAUNCH_CHECK("k_fy_resolve");
+    AURPPO_HIP_TRY(hipEventRecord(rng->ev_res, rng->fill_stream));
     rng->seq += 1;
+    return AURPPO_OK;
+}
+
+// The caller's stream sees the permutations only after the last resolve (which ran on the fill stream).
+static int join_resolves(aurppo_rng* rng, hipStream_t s) {
+    AURPPO_HIP_TRY(hipStreamWaitEvent(s, rng->ev_res, 0));
     return AURPPO_OK;
 }
 
@@ -632,6 +688,7 @@ static int restart_stream(aurppo_rng* rng, hipStream_t s) {
     AURPPO_LAUNCH_CHECK("k_mt_origin");
     rng->seq = 0;
     rng->primed_need = 0.0;
+    for (int k = 0; k < 3; ++k) rng->head_clean[k] = 0;
     return AURPPO_OK;
 }
 
@@ -647,13 +704,16 @@ extern "C" int aurppo_mt19937_create(aurppo_rng** out, uint32_t seed, int max_n,
     const double need = need_words(max_n);
     r->ring_cap = ((size_t)(4.0 * need) / kMtN + 8) * kMtN;
     const size_t nb = sizeof(int32_t) * (size_t)max_n;
+    r->head_cap = ((size_t)max_n + kClrChunk - 1) / kClrChunk * kClrChunk;
     hipError_t e = hipMalloc(&r->d_state, sizeof(uint32_t) * (kMtN + 1));
     if (e == hipSuccess) e = hipMalloc(&r->d_last, sizeof(uint32_t) * kMtN);
     if (e == hipSuccess) e = hipMalloc(&r->d_ring, sizeof(uint32_t) * (r->ring_cap + kRingMirror));
     if (e == hipSuccess) e = hipMalloc(&r->d_pos, sizeof(long long) * 32);
-    if (e == hipSuccess) e = hipMalloc(&r->d_j, nb);
-    if (e == hipSuccess) e = hipMalloc(&r->d_head, nb);
-    if (e == hipSuccess) e = hipMalloc(&r->d_next, nb);
+    for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+        e = hipMalloc(&r->d_j[k], nb);
+        if (e == hipSuccess) e = hipMalloc(&r->d_next[k], nb);
+    }
+    for (int k = 0; k < 3 && e == hipSuccess; ++k) e = hipMalloc(&r->d_head[k], sizeof(int32_t) * r->head_cap);
     if (e == hipSuccess) e = hipMalloc(&r->d_tmp, nb);
     if (e == hipSuccess) e = hipMalloc(&r->d_meta, sizeof(uint32_t) * (kMtN + 1));
     if (e == hipSuccess) {
@@ -666,7 +726,9 @@ extern "C" int aurppo_mt19937_create(aurppo_rng** out, uint32_t seed, int max_n,
     for (int k = 0; k < 2 && e == hipSuccess; ++k) {
         e = hipEventCreateWithFlags(&r->ev_fill[k], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&r->ev_acc[k], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&r->ev_link[k], hipEventDisableTiming);
     }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&r->ev_res, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&r->ev_sync, hipEventDisableTiming);
     if (e != hipSuccess) {
         aurppo_set_error("aurppo_mt19937_create: HIP resource allocation failed: %s", hipGetErrorString(e));
@@ -684,15 +746,19 @@ extern "C" int aurppo_mt19937_destroy(aurppo_rng* rng) {
     (void)hipFree(rng->d_last);
     (void)hipFree(rng->d_ring);
     (void)hipFree(rng->d_pos);
-    (void)hipFree(rng->d_j);
-    (void)hipFree(rng->d_head);
-    (void)hipFree(rng->d_next);
+    for (int k = 0; k < 2; ++k) {
+        (void)hipFree(rng->d_j[k]);
+        (void)hipFree(rng->d_next[k]);
+    }
+    for (int k = 0; k < 3; ++k) (void)hipFree(rng->d_head[k]);
     (void)hipFree(rng->d_tmp);
     (void)hipFree(rng->d_meta);
     for (int k = 0; k < 2; ++k) {
         if (rng->ev_fill[k]) (void)hipEventDestroy(rng->ev_fill[k]);
         if (rng->ev_acc[k]) (void)hipEventDestroy(rng->ev_acc[k]);
+        if (rng->ev_link[k]) (void)hipEventDestroy(rng->ev_link[k]);
     }
+    if (rng->ev_res) (void)hipEventDestroy(rng->ev_res);
     if (rng->ev_sync) (void)hipEventDestroy(rng->ev_sync);
     if (rng->fill_stream) (void)hipStreamDestroy(rng->fill_stream);
     delete rng;
@@ -765,6 +831,8 @@ extern "C" int aurppo_shuffle_i32(aurppo_rng* rng, int32_t* idx, int n, void* st
     hipStream_t s = (hipStream_t)stream;
     int rc = permute_once(rng, idx, rng->d_tmp, n, s);
     if (rc != AURPPO_OK) return rc;
+    rc = join_resolves(rng, s);
+    if (rc != AURPPO_OK) return rc;
     AURPPO_HIP_TRY(hipMemcpyAsync(idx, rng->d_tmp, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, s));
     return AURPPO_OK;
 }
@@ -785,5 +853,5 @@ extern "C" int aurppo_shuffle_epochs_i32(aurppo_rng* rng, int32_t* out, int n, i
         int rc = permute_once(rng, in, out + (size_t)e * n, n, s);
         if (rc != AURPPO_OK) return rc;
     }
-    return AURPPO_OK;
+    return join_resolves(rng, s);
 }
