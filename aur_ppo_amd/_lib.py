@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libaurppo_hip.so")
 SYMBOLS = (
     "aurppo_version", "aurppo_last_error", "aurppo_device_count", "aurppo_gae_f32", "aurppo_gae_pack_f32",
     "aurppo_mt19937_create", "aurppo_mt19937_destroy", "aurppo_mt19937_seed", "aurppo_mt19937_get_state",
-    "aurppo_mt19937_set_state", "aurppo_arange_i32", "aurppo_shuffle_i32", "aurppo_shuffle_epochs_i32",
+    "aurppo_mt19937_set_state", "aurppo_mt19937_status_f32", "aurppo_arange_i32", "aurppo_shuffle_i32", "aurppo_shuffle_epochs_i32",
     "aurppo_gather_f32", "aurppo_loss_workspace_bytes", "aurppo_loss_fwd_bwd_f32", "aurppo_loss_fwd_bwd_packed_f32",
     "aurppo_clip_workspace_bytes", "aurppo_grad_norm_clip_f32", "aurppo_mlp_workspace_bytes", "aurppo_mlp_ppo_step_f32",
     "aurppo_mlp_ppo_step_ev_f32", "aurppo_mlp_ppo_minibatch_f32", "aurppo_mlp_ppo_grad_f32", "aurppo_mlp_ppo_apply_f32", "aurppo_pack_records_f32", "aurppo_mlp_act_f32", "aurppo_clip_adam_f32",
@@ -49,6 +49,7 @@ def load() -> C.CDLL:
     lib.aurppo_mt19937_seed.argtypes = [vp, C.c_uint32, vp]
     lib.aurppo_mt19937_get_state.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_int32), vp]
     lib.aurppo_mt19937_set_state.argtypes = [vp, C.POINTER(C.c_uint32), C.c_int32, vp]
+    lib.aurppo_mt19937_status_f32.argtypes = [vp, vp, vp]
     lib.aurppo_arange_i32.argtypes = [vp, i32, vp]
     lib.aurppo_shuffle_i32.argtypes = [vp, vp, i32, vp]
     lib.aurppo_shuffle_epochs_i32.argtypes = [vp, vp, i32, i32, vp]

@@ -18,23 +18,35 @@ def weights_init(m):
 
 class base_encoder(nn.Module):
     """128x128 -> 64 -> 32 -> 16 -> 8 -> (3x3 valid) 6 -> 3 -> (3x3 valid) 1, channels
-    in-16-32-64-128-256-256-out_dim (src/nets/base_cnns.py:20-54)."""
+    in-16-32-64-128-256-256-out_dim (src/nets/base_cnns.py:20-54).
+
+    BUILD-DEFINED variant for 84x84 observations (BASELINE config 5; upstream has no encoder for that size -- its
+    equivariant one asserts 128, src/nets/equiv.py:159-162): 84 -> 42 -> 21 -> 10 -> 5 -> (3x3 valid) 3 -> (3x3 valid) 1,
+    channels in-16-32-64-128-256-out_dim -- the same conv3x3 + ReLU + maxpool2 blocks, one pooling stage fewer.  It makes
+    no equivariance claim and matches no upstream weights; it exists so the image-observation workload has a policy."""
 
     def __init__(self, obs_shape=(2, 128, 128), out_dim=1024):
         super().__init__()
         mods, c_in = [], obs_shape[0]
+        size = int(obs_shape[1])
+        if size not in (128, 84) or int(obs_shape[2]) != size:
+            raise ValueError(f"base_encoder: observations must be 128x128 (reference) or 84x84 (build-defined), got {obs_shape}")
         for c_out in (16, 32, 64, 128):
             mods += [nn.Conv2d(c_in, c_out, kernel_size=3, padding=1), nn.ReLU(inplace=True), nn.MaxPool2d(2)]
             c_in = c_out
-        mods += [nn.Conv2d(128, 256, kernel_size=3, padding=1), nn.ReLU(inplace=True),
-                 nn.Conv2d(256, 256, kernel_size=3, padding=0), nn.ReLU(inplace=True), nn.MaxPool2d(2),
-                 nn.Conv2d(256, out_dim, kernel_size=3, padding=0), nn.ReLU(inplace=True), nn.Flatten()]
+        if size == 128:
+            mods += [nn.Conv2d(128, 256, kernel_size=3, padding=1), nn.ReLU(inplace=True),
+                     nn.Conv2d(256, 256, kernel_size=3, padding=0), nn.ReLU(inplace=True), nn.MaxPool2d(2),
+                     nn.Conv2d(256, out_dim, kernel_size=3, padding=0), nn.ReLU(inplace=True), nn.Flatten()]
+        else:
+            mods += [nn.Conv2d(128, 256, kernel_size=3, padding=0), nn.ReLU(inplace=True),
+                     nn.Conv2d(256, out_dim, kernel_size=3, padding=0), nn.ReLU(inplace=True), nn.Flatten()]
         self.conv = nn.Sequential(*mods)
 
     def forward(self, x):
         return self.conv(x)
 
-    def forward_split(self, obs, state):
+    def forward_split(self, obs, state, memory_format=None):
         """Same result as ``forward(cat([obs, state tiled to a plane], 1))`` without materialising the
         concatenated (B, C+1, H, W) tensor: convolution is linear in its input channels, so the tiled
         plane contributes ``state * conv(ones)`` -- one tiny per-call map -- to the first layer."""
@@ -44,6 +56,8 @@ class base_encoder(nn.Module):
         ones = torch.ones((1, 1) + tuple(obs.shape[2:]), device=obs.device, dtype=obs.dtype)
         plane = torch.nn.functional.conv2d(ones, first.weight[:, c:c + 1], None, padding=first.padding)
         y = y + state.reshape(-1, 1, 1, 1) * plane + first.bias.reshape(1, -1, 1, 1)
+        if memory_format is not None:
+            y = y.contiguous(memory_format=memory_format)   # the layout the remaining convolutions then keep
         return self.conv[1:](y)
 
 
@@ -54,8 +68,8 @@ class base_critic(nn.Module):
         self.critic = nn.Sequential(nn.Linear(128, 128), nn.ReLU(inplace=True), nn.Linear(128, 1))
         self.apply(weights_init)
 
-    def forward(self, obs, state=None):
-        feats = self.conv(obs) if state is None else self.conv.forward_split(obs, state)
+    def forward(self, obs, state=None, memory_format=None):
+        feats = self.conv(obs) if state is None else self.conv.forward_split(obs, state, memory_format)
         return self.critic(feats)
 
 
@@ -66,6 +80,6 @@ class base_actor(nn.Module):
         self.mean_linear = nn.Linear(128, action_dim)
         self.apply(weights_init)
 
-    def forward(self, x, state=None):
-        feats = self.conv(x) if state is None else self.conv.forward_split(x, state)
+    def forward(self, x, state=None, memory_format=None):
+        feats = self.conv(x) if state is None else self.conv.forward_split(x, state, memory_format)
         return self.mean_linear(feats)

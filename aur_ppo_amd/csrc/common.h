@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/aurppo.h"
 
@@ -34,6 +35,21 @@ void aurppo_set_error(const char* fmt, ...);
     } while (0)
 
 constexpr int kWave = 64;
+
+// Per-device launch state (function attributes are per device; one process may drive several): slot of the calling
+// thread's current device in small static tables.
+constexpr int kMaxDevices = 16;
+static inline int aurppo_device_slot() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) d = 0;
+    return d;
+}
+// Diagnostic knobs (AURPPO_MLP_VARIANT ...) are read once per process; with AURPPO_TEST_KNOBS=1 (tests/conftest.py)
+// they are re-read on every call so that one test process can run both variants.
+static inline bool aurppo_live_knobs() {
+    static const bool live = [] { const char* e = getenv("AURPPO_TEST_KNOBS"); return e && *e == '1'; }();
+    return live;
+}
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

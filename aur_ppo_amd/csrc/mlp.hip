@@ -919,8 +919,12 @@ static int mlp_step_impl(const float* obs, const float* actions, const float* re
     hipStream_t s = (hipStream_t)stream;
     const int sb = stat_blocks_for(M);
     a.n_stat_blocks = sb;
-    const char* ve = getenv("AURPPO_MLP_VARIANT");   // read per call so that a test can run both variants in one process
-    const int variant = (ve && *ve == '1') ? 1 : 2;
+    static int variant_cached = 0;
+    if (!variant_cached || aurppo_live_knobs()) {
+        const char* ve = getenv("AURPPO_MLP_VARIANT");
+        variant_cached = (ve && *ve == '1') ? 1 : 2;
+    }
+    const int variant = variant_cached;
     a.w1op = wv.w1op;
     a.tile_counter = wv.tile_counter;
     double* sq_part = wv.sq_part;
@@ -938,16 +942,16 @@ static int mlp_step_impl(const float* obs, const float* actions, const float* re
     // 263 us with 0-2 spare CUs, 214 us with 8).  The two-set kernel hands tiles out dynamically, but it fills a
     // CU's register file, so a workgroup whose CU is taken starts late; 8 spare CUs measured 3.86-3.93 ms per
     // update against 4.09-4.10 ms with none.
-    static int cus = 0, spare_env = -1;
-    if (!cus) {
-        int dev = 0;
+    static int cus_of[kMaxDevices] = {0}, spare_env = -1;
+    const int dslot = aurppo_device_slot();
+    if (!cus_of[dslot]) {
         hipDeviceProp_t prop;
-        AURPPO_HIP_TRY(hipGetDevice(&dev));
-        AURPPO_HIP_TRY(hipGetDeviceProperties(&prop, dev));
-        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : kMaxGrid;
+        AURPPO_HIP_TRY(hipGetDeviceProperties(&prop, dslot));
+        cus_of[dslot] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : kMaxGrid;
         const char* e = getenv("AURPPO_MLP_SPARE_CUS");
         if (e && *e) spare_env = atoi(e);
     }
+    const int cus = cus_of[dslot];
     const int spare = spare_env >= 0 ? spare_env : 8;
     // AURPPO_MLP_VARIANT: 2 (default) = two tile sets per workgroup (mlp2.hip), 1 = one tile set (k_mlp_step below)
     int grid = cus - spare;
@@ -955,11 +959,11 @@ static int mlp_step_impl(const float* obs, const float* actions, const float* re
     if (grid < 1) grid = 1;
     const int tiles_per_wg = variant == 2 ? 2 : 1;
     if (grid > (n_tiles + tiles_per_wg - 1) / tiles_per_wg) grid = (n_tiles + tiles_per_wg - 1) / tiles_per_wg;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[kMaxDevices] = {false};
+    if (!attr_set[dslot]) {
         AURPPO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_step),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes()));
-        attr_set = true;
+        attr_set[dslot] = true;
     }
     if (ev_begin) AURPPO_HIP_TRY(hipEventRecord((hipEvent_t)ev_begin, s));
     if (variant == 2) {
@@ -1119,11 +1123,12 @@ extern "C" int aurppo_mlp_act_f32(const float* obs, const float* noise, int N, i
     a.L.n_params = n_params;
     for (int k = 0; k < (continuous ? 13 : 12); ++k)
         AURPPO_REQUIRE(layout_h[k] >= 0 && layout_h[k] < n_params, AURPPO_ESHAPE, "aurppo_mlp_act_f32: layout[%d]=%d", k, layout_h[k]);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[kMaxDevices] = {false};
+    const int dslot = aurppo_device_slot();
+    if (!attr_set[dslot]) {
         AURPPO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_act),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)act_lds_bytes()));
-        attr_set = true;
+        attr_set[dslot] = true;
     }
     hipLaunchKernelGGL(k_mlp_act, dim3((N + R - 1) / R), dim3(kThreads), act_lds_bytes(), (hipStream_t)stream, a);
     AURPPO_LAUNCH_CHECK("k_mlp_act");

@@ -716,11 +716,12 @@ namespace aurppo_mlp {
 size_t mlp_step2_lds_bytes() { return sizeof(float) * (size_t)(kSharedFloats + 2 * kSetFloats); }
 
 int launch_mlp_step2(const MlpArgs& a, int grid, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[kMaxDevices] = {false};
+    const int dslot = aurppo_device_slot();
+    if (!attr_set[dslot]) {
         AURPPO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_step2), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)mlp_step2_lds_bytes()));
-        attr_set = true;
+        attr_set[dslot] = true;
     }
     hipLaunchKernelGGL(k_mlp_step2, dim3(grid), dim3(kThreads2), mlp_step2_lds_bytes(), s, a);
     AURPPO_LAUNCH_CHECK("k_mlp_step2");

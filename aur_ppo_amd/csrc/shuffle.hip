@@ -553,6 +553,11 @@ __global__ void k_fy_resolve(const int32_t* __restrict__ j, const int32_t* __res
     out[i] = in ? in[src] : src;
 }
 
+// sticky "a shuffle ran out of draws" flag as a float, for the trainer's once-per-update scalar read
+__global__ void k_rng_status(const long long* __restrict__ posv, float* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = posv[2] != 0 ? 1.0f : 0.0f;
+}
+
 __global__ void k_arange(int32_t* idx, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) idx[i] = i;
@@ -580,7 +585,8 @@ static double need_words(int n) { return expected_draws(n) + 12.0 * sqrt(2.0 * (
 // more than half a CU's LDS (unused), which no two of them can get together.
 constexpr size_t kOwnCuLds = 81 * 1024;
 static hipError_t own_cu_setup() {
-    static bool done = false;
+    static bool done_of[kMaxDevices] = {false};
+    bool& done = done_of[aurppo_device_slot()];
     if (done) return hipSuccess;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mt_fill), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)kOwnCuLds);
@@ -810,6 +816,13 @@ extern "C" int aurppo_mt19937_set_state(aurppo_rng* rng, const uint32_t* key_h, 
     AURPPO_HIP_TRY(hipMemcpyAsync(rng->d_state, buf, sizeof(buf), hipMemcpyHostToDevice, s));
     AURPPO_HIP_TRY(hipStreamSynchronize(s));   // buf is a stack temporary
     return restart_stream(rng, s);
+}
+
+extern "C" int aurppo_mt19937_status_f32(aurppo_rng* rng, float* out, void* stream) {
+    AURPPO_REQUIRE(rng && out, AURPPO_EINVAL, "aurppo_mt19937_status_f32: null pointer");
+    hipLaunchKernelGGL(k_rng_status, dim3(1), dim3(64), 0, (hipStream_t)stream, rng->d_pos, out);
+    AURPPO_LAUNCH_CHECK("k_rng_status");
+    return AURPPO_OK;
 }
 
 extern "C" int aurppo_arange_i32(int32_t* idx, int n, void* stream) {

@@ -147,13 +147,13 @@ def make_vec_env(gym_id, num_envs, continuous, device, params):
 class SyntheticArmEnv:
     """Device-resident stand-in for BulletArm's ``EnvWrapper`` (src/utils/env_wrapper.py:7-59) with its
     interface: ``reset() -> (states, obs)``, ``step(actions, auto_reset=False) -> (states, obs, rewards,
-    dones)``, ``getNextAction() -> plan (N, 5)``.  Observations are (N, 1, H, W) heightmap-like images,
+    dones)``, ``getNextAction() -> plan (N, 5)``.  Observations are (N, C, H, W) heightmap-like images (C = 1 upstream),
     ``states`` the gripper open/closed flag.  Used when bulletarm is not installed (it is not part of
     this image) and for the synthetic image-observation configs of BASELINE.json."""
     device_native = True
 
-    def __init__(self, num_envs, device, obs_size=128, seed=4321, p_done=0.02, p_reward=0.05):
-        self.num_envs, self.device, self.obs_size = num_envs, torch.device(device), obs_size
+    def __init__(self, num_envs, device, obs_size=128, seed=4321, p_done=0.02, p_reward=0.05, channels=1):
+        self.num_envs, self.device, self.obs_size, self.channels = num_envs, torch.device(device), obs_size, channels
         self.p_done, self.p_reward = p_done, p_reward
         self.gen = torch.Generator(device=self.device)
         self.gen.manual_seed(seed)
@@ -161,7 +161,7 @@ class SyntheticArmEnv:
     def _draw(self):
         n, dev, g = self.num_envs, self.device, self.gen
         states = (torch.rand(n, device=dev, generator=g) < 0.5).float()
-        obs = torch.rand((n, 1, self.obs_size, self.obs_size), device=dev, generator=g)
+        obs = torch.rand((n, self.channels, self.obs_size, self.obs_size), device=dev, generator=g)
         return states, obs
 
     def reset(self):
@@ -202,7 +202,7 @@ def make_arm_envs(gym_id, num_envs, device, params, seed_offset=0):
             planner_config = {"random_orientation": True, "dpos": 0.02, "drot": 0.19634954084936207}
             return _BulletArmWrapper(env_factory.createEnvs(num_envs, gym_id, env_config, planner_config))
     return SyntheticArmEnv(num_envs, device, obs_size=int(params.get("obs_size", 128)),
-                           seed=int(params.get("env_seed", 4321)) + seed_offset)
+                           seed=int(params.get("env_seed", 4321)) + seed_offset, channels=int(params.get("obs_channels", 1)))
 
 
 class _BulletArmWrapper:

@@ -129,6 +129,12 @@ class MT19937:
         _check(_lib.load().aurppo_mt19937_set_state(self._h, key.ctypes.data_as(C.POINTER(C.c_uint32)), int(pos),
                                                     _stream()), "aurppo_mt19937_set_state")
 
+    def status_into(self, out):
+        """``out[0]`` (1-element fp32 device tensor) = 1 if a shuffle ran out of pre-generated draws since the last
+        (re)seed (its permutation is invalid), else 0.  No host sync: read it with the per-update scalars."""
+        _check(_lib.load().aurppo_mt19937_status_f32(self._h, _ptr(out), _stream()), "aurppo_mt19937_status_f32")
+        return out
+
     def shuffle_(self, idx):
         """In-place ``np.random.shuffle`` of an int32 device vector."""
         if idx.numel() == 0:

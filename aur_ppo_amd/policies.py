@@ -149,6 +149,21 @@ class ppoBullet(bulletArmPolicy):
         """PPO transitions carry value / expert_action / log_probs instead of next_* (:54-87);
         ``batch_size`` becomes the number of STEPS (len(batch) / num_processes)."""
         device = self.device if device is None else device
+        if isinstance(batch, dict):
+            # dense device-resident rollout (trainer.DenseTransitionBuffer.sample): the same fields as stacked tensors,
+            # time-major, already where they are needed -- no per-transition namedtuples, no numpy staging
+            n = batch["reward"].shape[0]
+            g = lambda k: batch[k].to(device)
+            states, obs, actions = g("state").long(), g("obs"), g("action")
+            obs = obs.unsqueeze(1) if obs.dim() == 3 else obs
+            rewards, non_final = g("reward").float(), 1.0 - g("done").float()
+            step_lefts, values = g("step_left"), g("value").float()
+            expert, log_probs = g("expert_action").float(), g("log_probs").float()
+            obs = obs / 255 * 0.4
+            self.loss_calc_dict.update(batch_size=int(n / self.num_processes), states=states, obs=obs, actions=actions,
+                                       rewards=rewards, non_final_masks=non_final, step_lefts=step_lefts, values=values,
+                                       expert_actions=expert, log_probs=log_probs)
+            return states, obs, actions, rewards, non_final, step_lefts, values, expert, log_probs
         st = self._stack
         states = st(batch, "state").long().to(device)
         obs = st(batch, "obs").to(device)
@@ -214,14 +229,15 @@ class ppoBullet(bulletArmPolicy):
             newlogprob.detach().reshape(-1).contiguous(), old_lp.reshape(-1).contiguous(), adv.contiguous(),
             newvalue.detach().reshape(-1).contiguous(), values.reshape(-1).contiguous(), ret.contiguous(),
             ent_rows.detach().contiguous(), self.clip_coeff, self.entropy_coeff, self.value_coeff, self.norm_adv, vmode)
-        return a, expert, newlogprob, ent_rows, newvalue, sc, g_lp, g_v, g_e
+        return a, expert, newlogprob, entropy, newvalue, sc, g_lp, g_v, g_e
 
     def compute_loss_pi(self, mb_inds):
-        """Policy loss (+ expert MSE) of one minibatch as a differentiable scalar, entropy, approx_kl."""
-        a, expert, newlogprob, ent_rows, _nv, sc, g_lp, _gv, _ge = self._minibatch(mb_inds)
+        """Policy loss (+ expert MSE) of one minibatch as a differentiable scalar, entropy (per element, as the actor's
+        ``sample`` returns it: upstream takes ``.mean()`` over all of it, :263), approx_kl."""
+        a, expert, newlogprob, entropy, _nv, sc, g_lp, _gv, _ge = self._minibatch(mb_inds)
         surrogate = (newlogprob.reshape(-1) * g_lp).sum() - (newlogprob.detach().reshape(-1) * g_lp).sum() + sc[self.ops.S_PG]
         loss = surrogate + self.expert_weight * nn.functional.mse_loss(a, expert)
-        return loss, ent_rows, sc[self.ops.S_KL]
+        return loss, entropy, sc[self.ops.S_KL]
 
     def compute_loss_v(self, mb_inds):
         _a, _e, _lp, _ent, newvalue, sc, _glp, g_v, _ge = self._minibatch(mb_inds)

@@ -25,7 +25,7 @@ from torch import nn
 from . import dist as D
 from .actor_critic import actor_critic
 from .envs import make_vec_env
-from .flat import FlatBucket
+from .flat import FlatAdamMixin, FlatBucket
 from .scalars import make_writer
 
 device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
@@ -57,7 +57,7 @@ class torch_buffer:
         return b_obs, b_logprobs, b_actions, b_advantages, b_returns, b_values
 
 
-class ppo:
+class ppo(FlatAdamMixin):
     """``ppo(params)`` as upstream (src/ppo.py:42-83).  Extra, optional ``params`` keys:
     ``obs_dim`` / ``act_dim`` / ``env_seed`` (Synthetic-* envs), ``log`` (False silences run logs),
     ``save`` (False skips the final pickle).  ``num_envs`` is the GLOBAL env count; under
@@ -136,6 +136,7 @@ class ppo:
         self.last_update = None
         self._probe_outs = None
         self._probe_mlp_outs = None
+        self._k2_flag = None
         # K7: fused gather + forward + loss + backward for the MLP actor-critic (None: per-op path)
         self._mlp = None
         if params.get("fused_mlp", True) and self.device.type == "cuda" and hasattr(ops, "mlp_layout"):
@@ -158,53 +159,6 @@ class ppo:
         self._rec = None           # (B,4) per-sample record written by K1
         self._rec_of = None
         self._probe = None         # bench.py hangs HIP-event pairs around the gather launches here
-
-    def _adam_setup(self):
-        """Flat Adam state for K6b (clip + Adam fused).  The torch optimizer object stays -- upstream code
-        reads ``optimizer.param_groups`` / ``state_dict()`` -- with its per-parameter state entries aliased to
-        views of the flat moment buffers and a shared device step counter."""
-        self._fused_adam = self.device.type == "cuda" and hasattr(self.ops, "clip_adam_")
-        if not self._fused_adam:
-            return
-        fp = self.bucket.flat_param
-        self._adam_m, self._adam_v = torch.zeros_like(fp), torch.zeros_like(fp)
-        self._adam_t = torch.zeros(1, device=self.device)
-        off = 0
-        for p in self.bucket.params:
-            k = p.numel()
-            self.optimizer.state[p] = {"step": self._adam_t, "exp_avg": self._adam_m[off:off + k].view_as(p),
-                                       "exp_avg_sq": self._adam_v[off:off + k].view_as(p)}
-            off += k
-
-    def _clip_and_step(self, norm_out, clip_n=None):
-        """clip_grad_norm_ + optimizer.step() (src/ppo.py:268-269)."""
-        if self._fused_adam:
-            g = self.optimizer.param_groups[0]
-            self.ops.clip_adam_(self.bucket.flat_param, self.bucket.flat_grad, self._adam_m, self._adam_v, self._lr_tensor,
-                                self._adam_t, self.max_grad_norm, clip_n, g["betas"], g["eps"], norm_out)
-        else:
-            fg = self.bucket.flat_grad if clip_n is None else self.bucket.flat_grad[:clip_n]
-            self.ops.grad_norm_clip_(fg, self.max_grad_norm, norm_out)
-            self.optimizer.step()
-
-    def set_lr(self, lr):
-        g = self.optimizer.param_groups[0]
-        if self._lr_tensor is not None:
-            self._lr_tensor.fill_(float(lr))
-            g["lr"] = self._lr_tensor
-        else:
-            g["lr"] = float(lr)
-
-    def _adopt_lr(self):
-        """Upstream writes ``optimizer.param_groups[0]["lr"] = lrnow`` (src/ppo.py:198).  If a caller did
-        that, move the value into the device scalar the (possibly captured) Adam step reads."""
-        g = self.optimizer.param_groups[0]
-        if self._lr_tensor is not None and g["lr"] is not self._lr_tensor:
-            self._lr_tensor.fill_(float(g["lr"]))
-            g["lr"] = self._lr_tensor
-
-    def get_lr(self):
-        return float(self.optimizer.param_groups[0]["lr"])
 
     # ------------------------------------------------------------------ seeding / shuffle stream
     def seed_all(self, seed=1):
@@ -553,7 +507,12 @@ class ppo:
         next_obs = self.envs.reset(seed=list(range(self.env_lo, self.env_lo + self.num_envs)))[0]
         next_obs = torch.as_tensor(next_obs, dtype=torch.float32).to(self.device)
         next_done = torch.zeros(self.num_envs, device=self.device)
-        for update in range(1, self.num_updates + 1):
+        first_update = 1
+        if self.params_dict.get("resume"):          # not upstream: continue an interrupted run (weights, Adam, RNG, update)
+            first_update = self.load_checkpoint(self.params_dict["resume"]) + 1
+            global_step = (first_update - 1) * self.batch_size * self.world
+        ck_path, ck_every = self.params_dict.get("checkpoint_path"), int(self.params_dict.get("checkpoint_every", 0))
+        for update in range(first_update, self.num_updates + 1):
             if self.anneal_lr:
                 frac = 1.0 - (update - 1.0) / self.num_updates
                 self.set_lr(frac * self.learning_rate)
@@ -563,6 +522,8 @@ class ppo:
             returns, advantages = self.advantages(next_obs, next_done)
             n_steps = self.update(returns, advantages)
             self._log_update(writer, returns, n_steps, global_step, start_time)
+            if ck_path and ck_every > 0 and update % ck_every == 0 and self.rank == 0:
+                self.save_checkpoint(ck_path, update=update)
         self.envs.close()
         writer.close()
         if self.params_dict.get("save", True) and self.rank == 0:
@@ -578,7 +539,16 @@ class ppo:
         b_values, b_returns = self.buffer.values.reshape(-1), returns.reshape(-1)
         var_y = b_returns.var(unbiased=False)
         ev = 1 - (b_returns - b_values).var(unbiased=False) / var_y
-        table = torch.cat([self._scalars[:n_steps].reshape(-1), self._norms[:n_steps], var_y.view(1), ev.view(1)]).cpu()
+        if self._k2_flag is None:
+            self._k2_flag = torch.zeros(1, device=self.device)
+        if self.rng is not None and hasattr(self.rng, "status_into"):
+            self.rng.status_into(self._k2_flag)       # sticky "a shuffle ran out of draws": rides in the same read
+        table = torch.cat([self._scalars[:n_steps].reshape(-1), self._norms[:n_steps], var_y.view(1), ev.view(1),
+                           self._k2_flag]).cpu()
+        if float(table[-1]) != 0.0:
+            raise RuntimeError("K2: a shuffle consumed more draws than were pre-generated (beyond 12 sigma of numpy's "
+                               "rejection sampling); the minibatch permutations of this update are invalid")
+        table = table[:-1]
         sc = table[:n_steps * ops.N_SCALARS].view(n_steps, ops.N_SCALARS).numpy()
         var_y, ev = float(table[-2]), float(table[-1])
         last = sc[-1]                                # logged values are the last minibatch's

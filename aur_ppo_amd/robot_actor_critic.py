@@ -19,8 +19,13 @@ _HALF_LOG_2PI = 0.5 * math.log(2.0 * math.pi)
 
 
 class robot_actor_critic(nn.Module):
-    def __init__(self, device, equivariant: bool, dx=0.02, dy=0.02, dz=0.02, dr=np.pi / 8, n_a=5, tau=0.001) -> None:
+    def __init__(self, device, equivariant: bool, dx=0.02, dy=0.02, dz=0.02, dr=np.pi / 8, n_a=5, tau=0.001,
+                 obs_shape=(1, 128, 128)) -> None:
+        """``obs_shape`` (extra, last): (channels, H, W) of the image observation -- (1, 128, 128) upstream; (3, 84, 84)
+        selects the build-defined encoder of base_cnns.base_encoder.  The gripper state adds one input plane."""
         super().__init__()
+        self.obs_shape = tuple(int(x) for x in obs_shape)
+        net_in = (self.obs_shape[0] + 1,) + self.obs_shape[1:]
         self.p_range = torch.tensor([0, 1])
         self.dtheta_range = torch.tensor([-dr, dr])
         self.dx_range = torch.tensor([-dx, dx])
@@ -28,16 +33,17 @@ class robot_actor_critic(nn.Module):
         self.dz_range = torch.tensor([-dz, dz])
         self.n_a = n_a
         self.device = device
+        self.memory_format = None      # torch.channels_last: NHWC activations behind the first convolution (trainer option)
         self.equivariant = equivariant
         if equivariant:
             raise NotImplementedError(
                 "equivariant=True needs e2cnn's C4 steerable convolutions (src/nets/equiv.py), a third-party "
                 "dependency that is not available offline and whose arithmetic no reference test pins")
-        self.network = base_encoder(obs_shape=(2, 128, 128), out_dim=128)   # unused upstream too; kept for state dicts
-        self.actor = base_actor()
+        self.network = base_encoder(obs_shape=net_in, out_dim=128)   # unused upstream too; kept for state dicts
+        self.actor = base_actor(obs_shape=net_in)
         self.actor.apply(weights_init)
         self.actor_logstd = nn.Parameter(torch.zeros(1, 5))
-        self.critic = base_critic()
+        self.critic = base_critic(obs_shape=net_in)
         self.critic.apply(weights_init)
 
     def forward(self, act):
@@ -45,7 +51,7 @@ class robot_actor_critic(nn.Module):
 
     def value(self, state, obs):
         # upstream tiles the gripper state to a plane and concatenates it (:58-59); folded into conv 1 here
-        return self.critic(obs.to(self.device), state.to(self.device))
+        return self.critic(obs.to(self.device), state.to(self.device), self.memory_format)
 
     @staticmethod
     def _scale(u, rng):
@@ -72,7 +78,7 @@ class robot_actor_critic(nn.Module):
 
     def evaluate(self, state, obs, action=None):
         state, obs = state.to(self.device), obs.to(self.device)
-        mean = self.actor(obs, state)
+        mean = self.actor(obs, state, self.memory_format)
         logstd = self.actor_logstd.expand_as(mean)
         std = torch.exp(logstd)
         if action is None:
@@ -81,8 +87,8 @@ class robot_actor_critic(nn.Module):
         log_prob = (-(z * z) / (2 * std * std) - logstd - _HALF_LOG_2PI).sum(1)
         entropy = (0.5 + _HALF_LOG_2PI + logstd).sum(1)
         unscaled_actions, actions = self.decodeActions(*[action[:, i] for i in range(self.n_a)])
-        return actions, unscaled_actions, log_prob, entropy, self.critic(obs, state)
+        return actions, unscaled_actions, log_prob, entropy, self.critic(obs, state, self.memory_format)
 
     def test_action(self, state, obs):
-        mean = torch.tanh(self.actor(obs.to(self.device), state.to(self.device)))
+        mean = torch.tanh(self.actor(obs.to(self.device), state.to(self.device), self.memory_format))
         return self.decodeActions(*[mean[:, i] for i in range(self.n_a)])

@@ -14,7 +14,8 @@ Same HIP kernels as ``ppo`` (K1-K6).  Upstream behaviour kept, with the SURVEY f
   * ``update`` slices minibatches with ``self.minibatch_size`` (src/robot_ppo.py:341);
   * the expert MSE term is between two buffer tensors (src/robot_ppo.py:397, F7): it has no gradient
     path and only shifted an un-returned ``loss`` value, so it is not computed;
-  * ``pretrain_update`` likewise back-propagates into a buffer tensor, not the policy (F7): kept as is.
+  * ``pretrain_update`` likewise back-propagates into a buffer tensor, not the policy (F7): no parameter receives a
+    gradient, upstream's ``optimizer.step()`` is a no-op there, and here the optimizer is not stepped at all.
 Deliberately different: ``log_probs`` is stored as (T, N) -- upstream's (T, N, action_shape) buffer
 only ran when num_envs == 5 by an accidental broadcast and then indexed the wrong elements (F5).
 """
@@ -29,7 +30,7 @@ from torch import nn
 
 from . import dist as D
 from .envs import make_arm_envs
-from .flat import FlatBucket
+from .flat import FlatAdamMixin, FlatBucket
 from .robot_actor_critic import robot_actor_critic
 from .scalars import make_writer
 
@@ -89,7 +90,7 @@ class store_returns:
         return R, n
 
 
-class robot_ppo:
+class robot_ppo(FlatAdamMixin):
     def __init__(self, params, ops=None, envs=None, eval_envs=None):
         self.params_dict = params
         self.all_steps = None
@@ -121,14 +122,17 @@ class robot_ppo:
         self.envs = envs if envs is not None else make_arm_envs(self.gym_id, self.num_envs, self.device, params, self.rank)
         self.eval_envs = eval_envs if eval_envs is not None else make_arm_envs(self.gym_id, 5, self.device, params, 1000)
         self.plot_index = 0
-        self.policy = robot_actor_critic(self.device, self.equivariant).to(self.device)
-        self.expert = robot_actor_critic(self.device, self.equivariant).to(self.device)
+        # extra, optional params: obs_size / obs_channels -- (1, 128, 128) upstream; (3, 84, 84) is BASELINE config 5's shape
+        self.obs_shape = (int(params.get("obs_channels", 1)), int(params.get("obs_size", 128)), int(params.get("obs_size", 128)))
+        self.policy = robot_actor_critic(self.device, self.equivariant, obs_shape=self.obs_shape).to(self.device)
+        self.expert = robot_actor_critic(self.device, self.equivariant, obs_shape=self.obs_shape).to(self.device)
+        if self.device.type == "cuda" and bool(params.get("channels_last", False)):
+            self.policy.memory_format = torch.channels_last      # NHWC activations from the first convolution on
         if self.world > 1:
             for p in self.policy.parameters():
                 torch.distributed.broadcast(p.data, src=0)
         self.action_dim = 5
         self.state_dim = 1
-        self.obs_shape = (1, int(params.get("obs_size", 128)), int(params.get("obs_size", 128)))
         self.buffer = torch_buffer(self.state_dim, self.obs_shape, self.action_dim, self.num_steps, self.num_envs)
         self.buffer.load_to_device(self.device)
         self.pretrain_buffer = None        # allocated by pretrain() (upstream builds it eagerly, on the host)
@@ -154,51 +158,24 @@ class robot_ppo:
         self._scalars = torch.zeros((n_steps, ops.N_SCALARS), device=self.device)
         self._norms = torch.zeros(n_steps, device=self.device)
 
-    # ------------------------------------------------------------------ helpers
-    def _adam_setup(self):
-        """Flat Adam state for K6b (clip + Adam fused).  The torch optimizer object stays -- upstream code
-        reads ``optimizer.param_groups`` / ``state_dict()`` -- with its per-parameter state entries aliased to
-        views of the flat moment buffers and a shared device step counter."""
-        self._fused_adam = self.device.type == "cuda" and hasattr(self.ops, "clip_adam_")
-        if not self._fused_adam:
-            return
-        fp = self.bucket.flat_param
-        self._adam_m, self._adam_v = torch.zeros_like(fp), torch.zeros_like(fp)
-        self._adam_t = torch.zeros(1, device=self.device)
-        off = 0
-        for p in self.bucket.params:
-            k = p.numel()
-            self.optimizer.state[p] = {"step": self._adam_t, "exp_avg": self._adam_m[off:off + k].view_as(p),
-                                       "exp_avg_sq": self._adam_v[off:off + k].view_as(p)}
-            off += k
-
-    def _clip_and_step(self, norm_out, clip_n=None):
-        """clip_grad_norm_ + optimizer.step() (src/ppo.py:268-269)."""
-        if self._fused_adam:
-            g = self.optimizer.param_groups[0]
-            self.ops.clip_adam_(self.bucket.flat_param, self.bucket.flat_grad, self._adam_m, self._adam_v, self._lr_tensor,
-                                self._adam_t, self.max_grad_norm, clip_n, g["betas"], g["eps"], norm_out)
-        else:
-            fg = self.bucket.flat_grad if clip_n is None else self.bucket.flat_grad[:clip_n]
-            self.ops.grad_norm_clip_(fg, self.max_grad_norm, norm_out)
-            self.optimizer.step()
-
-    def set_lr(self, lr):
-        g = self.optimizer.param_groups[0]
-        if self._lr_tensor is not None:
-            self._lr_tensor.fill_(float(lr))
-            g["lr"] = self._lr_tensor
-        else:
-            g["lr"] = float(lr)
-
-    def get_lr(self):
-        return float(self.optimizer.param_groups[0]["lr"])
-
+    # ------------------------------------------------------------------ helpers (Adam: flat.FlatAdamMixin)
     def seed_all(self, seed=1):
         random.seed(seed)
         np.random.seed(seed)
         torch.manual_seed(seed)
         self.rng = self.ops.MT19937(seed, max(self.batch_size, self.total_pretrain_steps), self.device)
+
+    # ---- checkpoint layout: upstream's three keys (src/robot_ppo.py:502-507) + what it forgets (``actor_logstd`` is a
+    # parameter of robot_actor_critic itself, in neither sub-module's state dict) + the resume state
+    def _checkpoint_nets(self):
+        return [("actor_state", self.policy.actor), ("critic_state", self.policy.critic)]
+
+    def _checkpoint_extra(self):
+        return {"actor_logstd": self.policy.actor_logstd.detach().cpu().clone()}
+
+    def _checkpoint_restore(self, sd):
+        if "actor_logstd" in sd:
+            self.policy.actor_logstd.copy_(sd["actor_logstd"])
 
     # ------------------------------------------------------------------ rollout (src/robot_ppo.py:161-197)
     def rewards_to_go(self, step, next_state, next_obs, global_step, writer):
@@ -292,7 +269,10 @@ class robot_ppo:
                 expert_loss = nn.functional.mse_loss(b_actions[mb].requires_grad_(True), b_true_actions[mb])
                 self.bucket.zero_grad()
                 expert_loss.backward()
-                self._clip_and_step(self._norms[:1], self.n_actor)
+                # upstream calls optimizer.step() here (src/robot_ppo.py:321-325) with every policy gradient None
+                # (zero_grad sets them to None in torch 2.1): the step skips every parameter, creates no Adam state
+                # and counts nothing.  Stepping the flat bucket on all-zero gradients would advance Adam's step
+                # counter, so the optimizer is left alone.
 
     def test_env(self, writer):
         test_returns = store_returns(self.num_envs, self.gamma)
@@ -323,6 +303,7 @@ class robot_ppo:
         if self.rng is None:
             self.seed_all(1)
         perms = self.rng.shuffle_epochs(batch_size, update_epochs)
+        self._adopt_lr()
         vmode = ops.VLOSS_CLIPPED if self.clip_vloss else ops.VLOSS_RETURNS     # src/robot_ppo.py:379-390
         M = self.minibatch_size                                                  # sic: not the argument (:341)
         step = 0
@@ -346,9 +327,22 @@ class robot_ppo:
                 D.allreduce_mean_(self.bucket.flat_grad, self.world)
                 self._clip_and_step(self._norms[step:step + 1], self.n_actor)
                 step += 1
-            if self.target_kl is not None and float(self._scalars[step - 1, ops.S_KL]) > self.target_kl:
-                break
-        sc = self._scalars[:step].cpu()
+            if self.target_kl is not None:
+                # the reference compares the LAST minibatch's approx_kl (src/robot_ppo.py:406-408); one process per GPU:
+                # the mean over ranks, so that every rank leaves the epoch loop together (the collectives stay matched)
+                kl = self._scalars[step - 1, ops.S_KL].clone()
+                if self.world > 1:
+                    torch.distributed.all_reduce(kl)
+                    kl /= self.world
+                if float(kl) > self.target_kl:
+                    break
+        flag = torch.zeros(1, device=self.device)
+        if hasattr(self.rng, "status_into"):
+            self.rng.status_into(flag)                # sticky "a shuffle ran out of draws": rides in the same read
+        both = torch.cat([self._scalars[:step].reshape(-1), flag]).cpu()
+        if float(both[-1]) != 0.0:
+            raise RuntimeError("K2: a shuffle consumed more draws than were pre-generated; this update's permutations are invalid")
+        sc = both[:-1].view(step, ops.N_SCALARS)
         self._last_scalars = sc.numpy()
         last = sc[-1]
         policy_losses.extend(sc[:, ops.S_PG].tolist())
@@ -378,7 +372,11 @@ class robot_ppo:
         next_state, next_obs = next_state.to(self.device), next_obs.to(self.device)
         next_done = torch.zeros(self.num_envs, device=self.device)
         policy_losses = []
-        for update in range(1, self.num_updates + 1):
+        first_update = 1
+        if self.params_dict.get("resume"):          # not upstream: continue an interrupted run (weights, Adam, RNG, update)
+            first_update = self.load_checkpoint(self.params_dict["resume"]) + 1
+            global_step = (first_update - 1) * self.batch_size * self.world
+        for update in range(first_update, self.num_updates + 1):
             if self.anneal_lr:
                 frac = 1.0 - (update - 1.0) / self.num_updates
                 self.set_lr(frac * self.learning_rate)
@@ -410,9 +408,8 @@ class robot_ppo:
         self.envs.close()
         writer.close()
         if self.save_file_path is not None and self.rank == 0:
-            save_state = {"actor_state": self.policy.actor.state_dict(), "critic_state": self.policy.critic.state_dict(),
-                          "optimizer_state": self.optimizer.state_dict()}
-            torch.save(save_state, self.save_file_path + "actor_critic_" + str(self.num_layers) + ".pt")
+            # upstream's keys (actor_state / critic_state / optimizer_state) plus actor_logstd, trainer_state, update
+            self.save_checkpoint(self.save_file_path + "actor_critic_" + str(self.num_layers) + ".pt", update=self.num_updates)
         return self.total_returns, self.total_episode_lengths, self.x_indices
 
     def moving_average(self, data, window_size):

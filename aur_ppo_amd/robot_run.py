@@ -54,6 +54,10 @@ def build_parser():
     p.add_argument("-sfp", "--save_file_path", type=str, default=None)
     p.add_argument("-render", "--render", type=str2bool, default=False, nargs="?", const=False)
     p.add_argument("-dpr", "--do_pretraining", type=str2bool, default=True, nargs="?", const=True)
+    # extras (not upstream; defaults reproduce upstream): image shape of the Synthetic-arm workloads, resume file
+    p.add_argument("--obs_size", type=int, default=128)
+    p.add_argument("--obs_channels", type=int, default=1)
+    p.add_argument("--resume", type=str, default=None)
     return p
 
 
@@ -61,7 +65,8 @@ PARAM_KEYS = ("gym_id", "seed", "num_steps", "gae", "total_timesteps", "anneal_l
               "num_envs", "num_minibatches", "entropy_coeff", "value_coeff", "clip_coeff", "clip_vloss", "max_grad_norm",
               "target_kl", "norm_adv", "capture_video", "hidden_dim", "continuous", "learning_rate", "exp_name",
               "num_layers", "dropout", "gamma", "track", "pretrain_episodes", "pretrain_steps", "pretrain_batch_size",
-              "expert_weight", "equivariant", "anneal_exp", "save_file_path", "render", "do_pretraining")
+              "expert_weight", "equivariant", "anneal_exp", "save_file_path", "render", "do_pretraining",
+              "obs_size", "obs_channels", "resume")
 
 
 def params_from_args(args):

@@ -98,6 +98,11 @@ int aurppo_mt19937_seed(aurppo_rng* rng, uint32_t seed, void* stream);
 /* Host copies of (key[624], pos) == np.random.get_state()[1:3].  These two synchronise `stream`. */
 int aurppo_mt19937_get_state(aurppo_rng* rng, uint32_t* key_h, int32_t* pos_h, void* stream);
 int aurppo_mt19937_set_state(aurppo_rng* rng, const uint32_t* key_h, int32_t pos_h, void* stream);
+/* out[0] (device) = 1.0f if any shuffle since the last (re)seed ran out of pre-generated draws (the inventory rule
+ * covers the expectation + 12 sigma of numpy's rejection sampling; beyond it the permutation is invalid and the flag
+ * sticks), else 0.0f.  Enqueued on `stream`, never synchronises: the trainer folds it into the one host read it makes
+ * per update (what np.random.shuffle, src/ppo.py:217, cannot fail at). */
+int aurppo_mt19937_status_f32(aurppo_rng* rng, float* out, void* stream);
 /* idx[i] = i  (np.arange, src/ppo.py:213) */
 int aurppo_arange_i32(int32_t* idx, int n, void* stream);
 /* In-place shuffle of idx[0..n), n <= max_n given at create. */

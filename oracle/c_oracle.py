@@ -8,7 +8,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "_build", "libaurppo_oracle.so")
+# AURPPO_ORACLE_SO selects another build of the same source (the ASan/UBSan one of `make -C oracle asan`)
+_SO = os.environ.get("AURPPO_ORACLE_SO") or os.path.join(_HERE, "_build", "libaurppo_oracle.so")
 _lib = None
 
 

@@ -480,3 +480,67 @@ def reference_robot_update(policy, optimizer, flat, hp, rng, minibatch_size):
             optimizer.step()
             rows.append([x.detach().item() for x in (loss, pg, vl, ent, old_kl, kl, clipfrac)])
     return np.array(rows, dtype=np.float64)
+
+
+def reference_ppobullet_update(pi, critic, pi_opt, v_opt, batch, next_obs, next_done, hp, num_processes):
+    """``ppoBullet.update`` (src/policies/ppoBullet.py:240-298 with :123-152, :180-238) on CPU torch tensors, with the
+    maths those lines intend where they do not run as written: the GAE recurrence with its body INSIDE the
+    time loop (:137-143 are dedented out of it upstream), and the policy loss evaluating the STORED actions
+    (``pi.sample(obs, actions)``; :183 re-samples, which makes the ratio meaningless).  Kept as written: no shuffling
+    (:259 ``np.arange``), policy step then value step per minibatch with separate Adam optimizers, ``clip_grad_value_``
+    at 1.0 (:272,:285), ``entropy.mean()`` over every element (:263), expert MSE added with ``expert_weight`` (:211-213),
+    value loss pre-multiplied by ``value_coeff`` (:236), KL early stop on the last minibatch (:293).
+
+    ``batch``: dict of flat time-major tensors (index t*N+n): states (B,), obs (B,C,H,W) already scaled, actions (B,A),
+    rewards, dones, values, log_probs (B,), expert (B,A).  Returns rows of (pi_loss, v_loss, approx_kl)."""
+    torch = _torch()
+    nn = torch.nn
+    N = num_processes
+    B = batch["rewards"].shape[0]
+    T = B // N
+    tile = lambda o, s: torch.cat([o, s.reshape(-1, 1, 1, 1).to(o.dtype).repeat(1, 1, o.shape[2], o.shape[3])], dim=1)
+    with torch.no_grad():
+        next_value = critic(next_obs).flatten()
+    ret, adv = gae(batch["rewards"].reshape(T, N).numpy(), batch["values"].reshape(T, N).numpy(),
+                   batch["dones"].reshape(T, N).numpy(), next_value.numpy(), next_done.numpy(), hp["gamma"],
+                   hp["gae_lambda"], GAE_MODE_GAE if hp.get("gae", True) else GAE_MODE_NORMAL)
+    returns, advantages = torch.from_numpy(ret).reshape(-1), torch.from_numpy(adv).reshape(-1)
+    clip = hp["clip_coeff"]
+    mbs = hp["minibatch_size"]
+    rows = []
+    for _ep in range(hp["num_update_epochs"]):
+        approx_kl = None
+        for start in range(0, B, mbs):
+            sl = slice(start, start + mbs)
+            obs = tile(batch["obs"][sl], batch["states"][sl])
+            a, newlogprob, _mean, entropy = pi.sample(obs, batch["actions"][sl])
+            log_ratio = newlogprob.reshape(-1) - batch["log_probs"][sl]
+            ratio = log_ratio.exp()
+            mb_adv = advantages[sl]
+            if hp.get("norm_adv", True):
+                mb_adv = (mb_adv - mb_adv.mean()) / (mb_adv.std() + 1e-8)
+            policy_loss = torch.max(-mb_adv * ratio, -mb_adv * torch.clamp(ratio, 1 - clip, 1 + clip)).mean()
+            loss = policy_loss + hp["expert_weight"] * nn.functional.mse_loss(a, batch["expert"][sl])
+            with torch.no_grad():
+                approx_kl = ((ratio - 1) - log_ratio).mean()
+            pi_loss = loss - hp["entropy_coeff"] * entropy.mean()
+            pi_opt.zero_grad()
+            pi_loss.backward()
+            nn.utils.clip_grad_value_(pi.parameters(), clip_value=1.0)
+            pi_opt.step()
+            newvalue = critic(obs).reshape(-1)
+            if hp.get("clip_vloss", False):
+                v_un = (newvalue - returns[sl]) ** 2
+                v_cl = (batch["values"][sl] + torch.clamp(newvalue - batch["values"][sl], -clip, clip) - returns[sl]) ** 2
+                v_loss = 0.5 * torch.max(v_un, v_cl).mean()
+            else:
+                v_loss = 0.5 * ((newvalue - returns[sl]) ** 2).mean()
+            v_loss = v_loss * hp["value_coeff"]
+            v_opt.zero_grad()
+            v_loss.backward()
+            nn.utils.clip_grad_value_(critic.parameters(), clip_value=1.0)
+            v_opt.step()
+            rows.append((pi_loss.item(), v_loss.item(), approx_kl.item()))
+        if approx_kl is not None and approx_kl > hp["target_kl"]:
+            break
+    return np.array(rows, dtype=np.float64), returns, advantages

@@ -3,6 +3,7 @@ import sys
 
 import pytest
 
+os.environ.setdefault("AURPPO_TEST_KNOBS", "1")   # the library re-reads its diagnostic env knobs on every call (tests flip them)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -38,6 +38,10 @@ class MT19937:
     def set_state(self, key, pos):
         self.rs.set_state(("MT19937", np.asarray(key, dtype=np.uint32), int(pos), 0, 0.0))
 
+    def status_into(self, out):
+        out.zero_()
+        return out
+
     def shuffle_(self, idx):
         x = idx.numpy()
         self.rs.shuffle(x)

@@ -122,3 +122,47 @@ def test_shard_envs_rejects_uneven_split():
     from aur_ppo_amd import dist as D
     with pytest.raises(ValueError):
         D.shard_envs(10, 0, 4)
+
+
+# ---------------------------------------------------------------------------------- robot_ppo, target_kl, 2 ranks
+def _robot_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from aur_ppo_amd import dist as D
+    from aur_ppo_amd.robot_ppo import robot_ppo
+    from aur_ppo_amd.robot_run import build_parser, params_from_args
+    from tests import oracle_ops
+    D.init_from_env(backend="gloo")
+    p = params_from_args(build_parser().parse_args([]))
+    # a threshold only ONE rank's local approx_kl would cross decides nothing: the mean over ranks does
+    p.update(gym_id="Synthetic-arm", num_envs=4, num_steps=4, total_timesteps=32, num_update_epochs=3, num_minibatches=2,
+             do_pretraining=False, log=False, device="cpu", obs_size=128, target_kl=float(os.environ["AURPPO_TEST_KL"]))
+    torch.manual_seed(7 + rank)
+    a = robot_ppo(p, ops=oracle_ops)
+    assert a.num_envs == 2 and a.world == 2
+    g = torch.Generator().manual_seed(11 + rank)
+    b = a.buffer
+    b.observations.copy_(torch.rand(b.observations.shape, generator=g))
+    b.actions.copy_(0.3 * torch.randn(b.actions.shape, generator=g))
+    b.rewards.copy_(torch.rand(b.rewards.shape, generator=g))
+    b.log_probs.copy_(-4 + (2.0 if rank == 0 else 0.01) * torch.randn(b.log_probs.shape, generator=g))   # rank 0: large KL
+    a.seed_all(1)
+    ret, adv = a.advantages(torch.zeros(2), torch.rand(2, 1, 128, 128, generator=g), torch.zeros(2), b, 4)
+    a.update(b.flatten(ret, adv), 3, a.batch_size, a.minibatch_size, [])
+    torch.save(dict(steps=a._last_scalars.shape[0], kl=float(a._last_scalars[-1][5]), p=a.bucket.flat_param.clone()),
+               os.path.join(out_dir, f"r{rank}.pt"))
+    D.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kl,expect", [("1e9", 6), ("-1", 2)])
+def test_robot_ppo_two_ranks_stop_on_the_reduced_kl_together(tmp_path, kl, expect, monkeypatch):
+    """Without the KL all-reduce, ranks whose local approx_kl differ leave the epoch loop at different epochs and the
+    next gradient all-reduce never completes (a hang).  Both ranks must run the same number of steps."""
+    monkeypatch.setenv("AURPPO_TEST_KL", kl)
+    mp.start_processes(_robot_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    r0, r1 = (torch.load(tmp_path / f"r{k}.pt") for k in range(2))
+    assert r0["steps"] == r1["steps"] == expect
+    assert torch.equal(r0["p"], r1["p"])
+    assert abs(r0["kl"] - r1["kl"]) > 1e-6          # the local values differ; the decision used their mean

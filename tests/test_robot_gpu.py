@@ -6,31 +6,32 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def test_robot_update_matches_cpu_restatement():
+@pytest.mark.parametrize("C,S", [(1, 128), (3, 84)], ids=["128x128x1_reference", "84x84x3_build_defined"])
+def test_robot_update_matches_cpu_restatement(C, S):
     from aur_ppo_amd.robot_actor_critic import robot_actor_critic
     from aur_ppo_amd.robot_ppo import robot_ppo
     from aur_ppo_amd.robot_run import build_parser, params_from_args
     from oracle import ppo_oracle as O
     p = params_from_args(build_parser().parse_args([]))
-    p.update(gym_id="Synthetic-arm", num_envs=4, num_steps=8, total_timesteps=64, num_update_epochs=2, num_minibatches=2,
-             do_pretraining=False, log=False, clip_vloss=True, entropy_coeff=0.01)
+    p.update(gym_id="Synthetic-arm", num_envs=8, num_steps=8, total_timesteps=128, num_update_epochs=2, num_minibatches=2,
+             do_pretraining=False, log=False, clip_vloss=True, entropy_coeff=0.01, obs_size=S, obs_channels=C)
     torch.manual_seed(2)
     agent = robot_ppo(p)
     assert agent.device.type == "cuda"
-    cpu = robot_actor_critic(torch.device("cpu"), False)
+    cpu = robot_actor_critic(torch.device("cpu"), False, obs_shape=(C, S, S))
     cpu.load_state_dict({k: v.cpu() for k, v in agent.policy.state_dict().items()})
     g = torch.Generator().manual_seed(9)
-    T, N = 8, 4
-    buf = dict(states=(torch.rand(T, N, generator=g) < 0.5).float(), observations=torch.rand(T, N, 1, 128, 128, generator=g),
+    T, N = 8, 8
+    buf = dict(states=(torch.rand(T, N, generator=g) < 0.5).float(), observations=torch.rand(T, N, C, S, S, generator=g),
                actions=0.3 * torch.randn(T, N, 5, generator=g), true_actions=torch.zeros(T, N, 5),
                rewards=(torch.rand(T, N, generator=g) < 0.3).float(), terminals=(torch.rand(T, N, generator=g) < 0.1).float())
     with torch.no_grad():
-        _, _, lp, _, v = cpu.evaluate(buf["states"].view(-1), buf["observations"].view(-1, 1, 128, 128), buf["actions"].view(-1, 5))
+        _, _, lp, _, v = cpu.evaluate(buf["states"].view(-1), buf["observations"].view(-1, C, S, S), buf["actions"].view(-1, 5))
     buf["log_probs"] = (lp.view(T, N) + 0.05 * torch.randn(T, N, generator=g))
     buf["values"] = v.view(T, N).clone()
     for k, t in buf.items():
         getattr(agent.buffer, k).copy_(t)
-    next_state, next_obs = (torch.rand(N, generator=g) < 0.5).float(), torch.rand(N, 1, 128, 128, generator=g)
+    next_state, next_obs = (torch.rand(N, generator=g) < 0.5).float(), torch.rand(N, C, S, S, generator=g)
     next_done = torch.zeros(N)
     agent.seed_all(1)
     ret, adv = agent.advantages(next_state.cuda(), next_obs.cuda(), next_done.cuda(), agent.buffer, T)
@@ -42,7 +43,7 @@ def test_robot_update_matches_cpu_restatement():
     np.testing.assert_allclose(adv.cpu().numpy(), adv_o, atol=1e-5)
     assert float(adv[-1].abs().max()) == 0.0
     out = agent.update(agent.buffer.flatten(ret, adv), 2, agent.batch_size, agent.minibatch_size, [])
-    flat_cpu = (buf["states"].view(-1), buf["observations"].view(-1, 1, 128, 128), buf["log_probs"].reshape(-1),
+    flat_cpu = (buf["states"].view(-1), buf["observations"].view(-1, C, S, S), buf["log_probs"].reshape(-1),
                 buf["actions"].view(-1, 5), torch.from_numpy(adv_o).reshape(-1), torch.from_numpy(ret_o).reshape(-1),
                 buf["values"].reshape(-1), buf["true_actions"].view(-1, 5))
     opt = torch.optim.Adam(cpu.parameters(), lr=p["learning_rate"], eps=1e-5)

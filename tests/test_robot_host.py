@@ -67,3 +67,43 @@ def test_train_end_to_end_with_pretraining_and_update_return_signature():
     assert len(out) == 6 and len(out[5]) == 2
     np.testing.assert_allclose(float(out[1]), a._last_scalars[-1][2] * a.value_coeff, rtol=1e-6)
     assert a.n_actor == sum(p.numel() for p in a.policy.actor.parameters())
+
+
+def test_pretrain_update_leaves_the_policy_optimizer_untouched():
+    """upstream's optimizer.step() in pretrain_update is a no-op (every policy gradient is None), so real
+    training starts with Adam's bias corrections at t = 1 -- the optimizer must not have been stepped."""
+    torch.manual_seed(0)
+    a = robot_ppo(_params(do_pretraining=True, num_update_epochs=2), ops=oracle_ops)
+    before = a.bucket.flat_param.clone()
+    a.seed_all(1)
+    ns, no, nd = a.pretrain()
+    ret, adv = a.advantages(ns, no, nd, a.pretrain_buffer, a.pretrain_steps)
+    key0, pos0 = a.rng.get_state()
+    a.pretrain_update(a.pretrain_buffer.flatten(ret, adv), 2, a.pretrain_batch_size, a.pretrain_minibatch_size)
+    assert torch.equal(before, a.bucket.flat_param)
+    assert all(len(s) == 0 or float(s["step"]) == 0 for s in a.optimizer.state.values()), "Adam step counter advanced"
+    assert a.rng.get_state()[1] != pos0 or not np.array_equal(a.rng.get_state()[0], key0)     # the shuffles were still drawn
+
+
+def test_build_defined_84x84x3_policy_and_env():
+    a = robot_ppo(_params(obs_size=84, obs_channels=3), ops=oracle_ops)
+    assert a.buffer.observations.shape == (6, 2, 3, 84, 84) and a.policy.obs_shape == (3, 84, 84)
+    s, o = a.envs.reset()
+    assert o.shape == (2, 3, 84, 84)
+    acts, unscaled, lp, ent, v = a.policy.evaluate(s, o)
+    assert acts.shape == (2, 5) and lp.shape == (2,) and v.shape == (2, 1)
+    # state plane folded into conv 1 == the materialised concat (the reference's formulation, robot_actor_critic.py:58-59)
+    x = torch.cat([o, s.reshape(-1, 1, 1, 1).repeat(1, 1, 84, 84)], dim=1)
+    np.testing.assert_allclose(a.policy.critic(o, s).detach().numpy(), a.policy.critic(x).detach().numpy(), rtol=1e-4, atol=1e-5)
+    import pytest
+    with pytest.raises(ValueError):
+        robot_ppo(_params(obs_size=100), ops=oracle_ops)
+
+
+def test_channels_last_option_gives_the_same_numbers():
+    torch.manual_seed(1)
+    a = robot_ppo(_params(), ops=oracle_ops)
+    s, o = a.envs.reset()
+    v0 = a.policy.value(s, o).detach().clone()
+    a.policy.memory_format = torch.channels_last
+    np.testing.assert_allclose(a.policy.value(s, o).detach().numpy(), v0.numpy(), rtol=1e-4, atol=1e-5)

@@ -1,22 +1,43 @@
-"""BASELINE config 3's shape with the non-equivariant CNN actor-critic (the equivariant one needs e2cnn): robot_ppo's GAE +
-update (src/robot_ppo.py:329-408) on synthetic image rollouts, N envs x T steps of (1,128,128) observations."""
-import os, sys, time
+"""robot_ppo's GAE + update (src/robot_ppo.py:329-408) on synthetic image rollouts with the plain-CNN actor-critic (the
+equivariant one needs e2cnn): BASELINE config 3's shape (N=256, T=128, (1,128,128)) and config 5's per-GPU shard
+(N=2048/8=256, T=64, (3,84,84), build-defined encoder).  Prints one JSON line per run with the conv-FLOP bound.
+
+    python tools/bench_robot.py --config 3 [--channels-last] [--miopen-find] [--updates 2]
+"""
+import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+T0 = time.time()
+def note(msg):
+    print(f"[bench_robot {time.time() - T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+ap = argparse.ArgumentParser()
+ap.add_argument("--config", type=int, default=3, choices=(3, 5))
+ap.add_argument("--envs", type=int, default=0)
+ap.add_argument("--steps", type=int, default=0)
+ap.add_argument("--epochs", type=int, default=4)
+ap.add_argument("--minibatches", type=int, default=4)
+ap.add_argument("--updates", type=int, default=2)
+ap.add_argument("--channels-last", action="store_true")
+ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark: let MIOpen time its solvers per shape")
+args = ap.parse_args()
 from aur_ppo_amd.robot_ppo import robot_ppo
 from aur_ppo_amd.robot_run import build_parser, params_from_args
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-T = int(sys.argv[2]) if len(sys.argv) > 2 else 128
-E = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+C, S = (1, 128) if args.config == 3 else (3, 84)
+N = args.envs or 256
+T = args.steps or (128 if args.config == 3 else 64)
+E = args.epochs
+torch.backends.cudnn.benchmark = bool(args.miopen_find)
 p = params_from_args(build_parser().parse_args([]))
-p.update(gym_id="Synthetic-arm", num_envs=N, num_steps=T, total_timesteps=N * T * 4, num_update_epochs=E, num_minibatches=4,
-         do_pretraining=False, log=False)
+p.update(gym_id="Synthetic-arm", num_envs=N, num_steps=T, total_timesteps=N * T * 4, num_update_epochs=E, num_minibatches=args.minibatches,
+         do_pretraining=False, log=False, obs_size=S, obs_channels=C, channels_last=args.channels_last)
 torch.manual_seed(1)
 a = robot_ppo(p)
+note("trainer built")
 g = torch.Generator(device="cuda").manual_seed(3)
 b = a.buffer
 b.states.copy_((torch.rand(T, N, device="cuda", generator=g) < 0.5).float())
-b.observations.copy_(torch.rand(T, N, 1, 128, 128, device="cuda", generator=g))
+for t in range(T):
+    b.observations[t].copy_(torch.rand(N, C, S, S, device="cuda", generator=g))
 b.actions.copy_(0.3 * torch.randn(T, N, 5, device="cuda", generator=g))
 b.rewards.copy_((torch.rand(T, N, device="cuda", generator=g) < 0.3).float())
 b.terminals.copy_((torch.rand(T, N, device="cuda", generator=g) < 0.02).float())
@@ -24,15 +45,31 @@ with torch.no_grad():
     for t in range(T):
         _, _, lp, _, v = a.policy.evaluate(b.states[t], b.observations[t], b.actions[t])
         b.log_probs[t].copy_(lp); b.values[t].copy_(v.flatten())
+note("rollout values filled (T forward passes at N rows: MIOpen picks/compiles its solvers on first use of a shape)")
 ns, no, nd = b.states[0].clone(), b.observations[0].clone(), torch.zeros(N, device="cuda")
 a.seed_all(1)
 def step():
     ret, adv = a.advantages(ns, no, nd, b, T)
     a.update(b.flatten(ret, adv), E, a.batch_size, a.minibatch_size, [])
 step(); torch.cuda.synchronize()
+note("first update done (solvers for the minibatch shapes chosen)")
 t0 = time.perf_counter()
-K = 3
-for _ in range(K): step()
+for _ in range(args.updates): step()
 torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / K
-print(f"robot_ppo CNN policy, N={N} T={T} E={E}, 4 minibatches of {a.minibatch_size}: {dt * 1e3:.1f} ms per GAE+update -> {N * T / dt / 1e6:.3f} M env-steps/s")
+dt = (time.perf_counter() - t0) / args.updates
+# forward conv FLOPs of ONE encoder per sample (2 * out_pixels * out_ch * in_ch * 9), two encoders (actor, critic), fwd + bwd ~ 3x
+def conv_flops(size, cin):
+    f, c_in, s = 0, cin, size
+    for c_out in (16, 32, 64, 128):
+        f += 2 * s * s * c_out * c_in * 9; c_in = c_out; s //= 2
+    if size == 128:
+        f += 2 * s * s * 256 * 128 * 9; s -= 2; f += 2 * s * s * 256 * 256 * 9; s //= 2; s -= 2; f += 2 * s * s * 128 * 256 * 9
+    else:
+        s -= 2; f += 2 * s * s * 256 * 128 * 9; s -= 2; f += 2 * s * s * 128 * 256 * 9
+    return f
+flops = 3 * 2 * conv_flops(S, C + 1) * N * T * E
+print(json.dumps({"workload": f"robot_ppo CNN policy, config {args.config}: N={N} T={T} obs=({C},{S},{S}) E={E}, {args.minibatches} minibatches of {a.minibatch_size}",
+                  "channels_last": args.channels_last, "miopen_find": args.miopen_find, "ms_per_update": round(dt * 1e3, 1),
+                  "env_steps_per_s": round(N * T / dt, 1), "conv_tflop_per_update": round(flops / 1e12, 1),
+                  "conv_bound_ms_at_157_tflops": round(flops / 157.3e12 * 1e3, 1),
+                  "frac_of_fp32_mfma_peak": round(flops / dt / 157.3e12, 3)}))
