@@ -1,7 +1,9 @@
 """Plain-CNN encoder / actor / critic of the robot policy with the reference's module layout and
 state-dict keys (src/nets/base_cnns.py:12-84): ``base_encoder.conv.{0,3,6,9,12,14,17}``,
 ``base_actor.{conv,mean_linear}``, ``base_critic.{conv,critic.{0,2}}``; xavier init as upstream.
-Stock PyTorch-ROCm (MIOpen convolutions): host code, not a custom kernel."""
+The convolutions are stock PyTorch-ROCm (MIOpen); on the GPU the element-wise tail of every conv + ReLU + max-pool block
+(bias add, ReLU, 2x2 max-pool, and for the first block the tiled gripper-state channel) is K9, one fused HIP pass forward
+and one backward (csrc/pool.hip): rocprof put 53 % of robot_ppo.update's GPU time in those memory-bound passes."""
 from __future__ import annotations
 
 import torch
@@ -43,8 +45,33 @@ class base_encoder(nn.Module):
                      nn.Conv2d(256, out_dim, kernel_size=3, padding=0), nn.ReLU(inplace=True), nn.Flatten()]
         self.conv = nn.Sequential(*mods)
 
+    fused_pool = True      # K9 on CUDA tensors (False: the stock torch ops everywhere, for A/B runs)
+
+    def _blocks(self, x, start, scale=None, plane=None, first_weight=None):
+        """Run self.conv[start:] on x; on the GPU every (Conv2d, ReLU, MaxPool2d(2)) triple becomes convolution without bias
+        + K9.  ``scale`` / ``plane`` / ``first_weight`` belong to the first convolution when it runs in split form."""
+        mods = list(self.conv)
+        use = self.fused_pool and x.is_cuda
+        if use:
+            from . import hip_ops as H      # raises without the built library: there is no silent fallback on a GPU box
+        i = start
+        while i < len(mods):
+            m = mods[i]
+            triple = (isinstance(m, nn.Conv2d) and i + 2 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                      and isinstance(mods[i + 2], nn.MaxPool2d) and mods[i + 2].kernel_size in (2, (2, 2))
+                      and mods[i + 2].stride in (2, (2, 2)) and mods[i + 2].padding in (0, (0, 0)))
+            if use and triple:
+                w = first_weight if (i == start and first_weight is not None) else m.weight
+                z = torch.nn.functional.conv2d(x, w, None, stride=m.stride, padding=m.padding)
+                x = H.bias_relu_pool2(z, m.bias, scale if i == start else None, plane if i == start else None)
+                i += 3
+            else:
+                x = m(x)
+                i += 1
+        return x
+
     def forward(self, x):
-        return self.conv(x)
+        return self._blocks(x, 0)
 
     def forward_split(self, obs, state, memory_format=None):
         """Same result as ``forward(cat([obs, state tiled to a plane], 1))`` without materialising the
@@ -52,13 +79,19 @@ class base_encoder(nn.Module):
         plane contributes ``state * conv(ones)`` -- one tiny per-call map -- to the first layer."""
         first = self.conv[0]
         c = obs.shape[1]
+        if self.fused_pool and obs.is_cuda and memory_format is None:
+            # K9 adds state * plane and the bias while it applies ReLU and the pool: the block's output is written once
+            ones = torch.ones((1, 1) + tuple(obs.shape[2:]), device=obs.device, dtype=obs.dtype)
+            plane = torch.nn.functional.conv2d(ones, first.weight[:, c:c + 1], None, padding=first.padding)
+            return self._blocks(obs, 0, scale=state.reshape(-1).to(obs.dtype), plane=plane, first_weight=first.weight[:, :c])
         y = torch.nn.functional.conv2d(obs, first.weight[:, :c], None, padding=first.padding)
         ones = torch.ones((1, 1) + tuple(obs.shape[2:]), device=obs.device, dtype=obs.dtype)
         plane = torch.nn.functional.conv2d(ones, first.weight[:, c:c + 1], None, padding=first.padding)
         y = y + state.reshape(-1, 1, 1, 1) * plane + first.bias.reshape(1, -1, 1, 1)
         if memory_format is not None:
             y = y.contiguous(memory_format=memory_format)   # the layout the remaining convolutions then keep
-        return self.conv[1:](y)
+            return self.conv[1:](y)
+        return self._blocks(y, 1)
 
 
 class base_critic(nn.Module):

@@ -494,3 +494,49 @@ def clip_adam_(flat_param, flat_grad, exp_avg, exp_avg_sq, lr_dev, step_dev, max
                                     float(eps), _ptr(out_norm), C.c_void_p(ws.data_ptr()), _stream()),
            "aurppo_clip_adam_f32")
     return out_norm
+
+
+# ------------------------------------------------------------------ K9
+class _BiasReluPool2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, bias, scale, plane):
+        lib = _lib_or_raise()
+        x = x.contiguous()
+        B, Cc, Hh, Ww = x.shape
+        y = torch.empty((B, Cc, Hh // 2, Ww // 2), dtype=torch.float32, device=x.device)
+        mask = torch.empty((B, Cc, Hh // 2, Ww // 2), dtype=torch.uint8, device=x.device)
+        if plane is not None:
+            plane = plane.detach().reshape(Cc, Hh, Ww).contiguous()
+            scale = scale.detach().reshape(B).contiguous()
+        _check(lib.aurppo_bias_relu_pool2_fwd_f32(_ptr(x.detach()), _optr(bias.detach().contiguous() if bias is not None else None),
+                                                  _optr(scale), _optr(plane), _ptr(y), C.c_void_p(mask.data_ptr()), B, Cc, Hh, Ww,
+                                                  _stream()), "aurppo_bias_relu_pool2_fwd_f32")
+        ctx.save_for_backward(mask, scale if plane is not None else None)
+        ctx.shape = (B, Cc, Hh, Ww)
+        ctx.has = (bias is not None, plane is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib_or_raise()
+        mask, scale = ctx.saved_tensors
+        B, Cc, Hh, Ww = ctx.shape
+        dy = dy.contiguous()
+        dx = torch.empty((B, Cc, Hh, Ww), dtype=torch.float32, device=dy.device)
+        part = torch.empty((B, Cc), dtype=torch.float32, device=dy.device) if ctx.has[0] else None
+        _check(lib.aurppo_bias_relu_pool2_bwd_f32(_ptr(dy), C.c_void_p(mask.data_ptr()), _ptr(dx), _optr(part), B, Cc, Hh, Ww,
+                                                  _stream()), "aurppo_bias_relu_pool2_bwd_f32")
+        dbias = part.sum(0) if part is not None else None
+        dplane = None
+        if ctx.has[1]:
+            dplane = torch.empty((1, Cc, Hh, Ww), dtype=torch.float32, device=dy.device)
+            _check(lib.aurppo_weighted_batch_sum_f32(_ptr(dx), _ptr(scale), _ptr(dplane), B, Cc * Hh * Ww, _stream()),
+                   "aurppo_weighted_batch_sum_f32")
+        return dx, dbias, None, dplane
+
+
+def bias_relu_pool2(x, bias=None, scale=None, plane=None):
+    """K9: ``max_pool2d(relu(x + bias[c] + scale[b] * plane[c]), 2)`` in one pass (and one for the backward): the tail of a
+    convolution block of src/nets/base_cnns.py:28-45; ``scale`` / ``plane`` carry the tiled gripper-state channel of
+    src/models/robot_actor_critic.py:58-59 (no gradient flows to ``scale``, the state is an input)."""
+    return _BiasReluPool2.apply(x, bias, scale, plane)

@@ -249,6 +249,24 @@ int aurppo_clip_adam_f32(float* params, float* grads, float* exp_avg, float* exp
                          double beta1, double beta2, double eps, float* out_norm, void* workspace,
                          void* stream);
 
+/* ---- K9: bias + gripper-state plane + ReLU + 2x2 max-pool, fused (robot policy encoder) -----------------------
+ * Replaces, behind each convolution of the plain-CNN encoder (src/nets/base_cnns.py:28-45), the convolution's bias
+ * add, `nn.ReLU` and `nn.MaxPool2d(2)`, and for the first block the tiled gripper-state input channel of
+ * src/models/robot_actor_critic.py:58-59,106-107 (convolution is linear in its input channels: the tiled plane
+ * contributes scale[b] * plane[c,h,w], plane = conv(ones, W[:, state channel])).
+ *   forward:  y[b,c,ho,wo] = max(0, max over the 2x2 window of  x + bias[c] + scale[b]*plane[c,h,w])
+ *             mask = window position of the FIRST maximum (0..3, row-major, torch's tie rule), 4 if it is <= 0
+ *   backward: dx = dy routed to the masked position (zero elsewhere, zero on an odd trailing row / column),
+ *             dbias_part[b*C + c] = sum of dy over that plane's live pooled elements (sum over b gives d bias)
+ * x, dx: (B,C,H,W) contiguous; y, dy, mask: (B,C,H/2,W/2) (floor).  bias (C), scale (B) + plane (C,H,W) may be NULL
+ * (scale and plane together).  aurppo_weighted_batch_sum_f32: out[k] = sum_b w[b] * x[b,k] -- the gradient of `plane`
+ * from dx and scale. */
+int aurppo_bias_relu_pool2_fwd_f32(const float* x, const float* bias, const float* scale, const float* plane, float* y,
+                                   uint8_t* mask, int B, int C, int H, int W, void* stream);
+int aurppo_bias_relu_pool2_bwd_f32(const float* dy, const uint8_t* mask, float* dx, float* dbias_part, int B, int C,
+                                   int H, int W, void* stream);
+int aurppo_weighted_batch_sum_f32(const float* x, const float* w, float* out, int B, int64_t K, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -374,3 +374,58 @@ def test_clip_adam_matches_torch_clip_then_adam(H, n, clip_n):
     st = opt.state[p_ref]
     torch.testing.assert_close(m, st["exp_avg"], rtol=1e-5, atol=1e-9)
     torch.testing.assert_close(v, st["exp_avg_sq"], rtol=1e-5, atol=1e-12)
+
+
+# ---------------------------------------------------------------------------------- K9: bias + state plane + ReLU + max-pool
+@pytest.mark.parametrize("B,C,Hh,Ww,with_plane", [(3, 16, 128, 128, True), (2, 5, 84, 84, True), (4, 7, 42, 42, False),
+                                                  (3, 4, 21, 21, False), (2, 3, 10, 10, False), (5, 8, 6, 6, False),
+                                                  (2, 2, 7, 9, True), (1, 1, 2, 2, False)])
+def test_bias_relu_pool2_matches_torch_ops_forward_and_backward(H, B, C, Hh, Ww, with_plane):
+    """K9 vs the op chain it replaces (src/nets/base_cnns.py:28-45: conv bias, nn.ReLU, nn.MaxPool2d(2); plane term of
+    src/models/robot_actor_critic.py:58-59) in plain PyTorch fp32, values AND gradients, odd sizes and ties included."""
+    import torch.nn.functional as F
+    g = torch.Generator(device="cuda").manual_seed(B * 1000 + Hh)
+    x = torch.randn(B, C, Hh, Ww, device="cuda", generator=g)
+    x[0, 0].fill_(0.25)                       # a plane of ties: the first window element must win
+    x[-1, -1].fill_(-1.0)                     # a dead plane
+    bias = torch.randn(C, device="cuda", generator=g)
+    scale = (torch.rand(B, device="cuda", generator=g) < 0.5).float() if with_plane else None
+    plane = torch.randn(1, C, Hh, Ww, device="cuda", generator=g) if with_plane else None
+    leaves = [t.clone().requires_grad_(True) for t in (x, bias)] + ([plane.clone().requires_grad_(True)] if with_plane else [])
+    # association of base_encoder.forward_split: (conv + state * plane) + bias
+    ref_in = ((leaves[0] + scale.view(-1, 1, 1, 1) * leaves[2]) if with_plane else leaves[0]) + leaves[1].view(1, -1, 1, 1)
+    ref = F.max_pool2d(F.relu(ref_in), 2)
+    w = torch.randn(ref.shape, device="cuda", generator=g)
+    (ref * w).sum().backward()
+    mine = [t.clone().requires_grad_(True) for t in (x, bias)] + ([plane.clone().requires_grad_(True)] if with_plane else [])
+    y = H.bias_relu_pool2(mine[0], mine[1], scale, mine[2] if with_plane else None)
+    (y * w).sum().backward()
+    assert y.shape == ref.shape
+    assert torch.equal(y, ref)                                  # same additions in the same order: bit-exact
+    assert torch.equal(mine[0].grad, leaves[0].grad)            # routing only
+    # the bias gradient sums B*Ho*Wo terms: torch in fp32 (cascade), K9 in fp64 partials -- compare at the sum's own rounding level
+    n_terms = B * (Hh // 2) * (Ww // 2)
+    torch.testing.assert_close(mine[1].grad, leaves[1].grad, rtol=1e-5, atol=2e-7 * n_terms ** 0.5 * float(w.abs().max()) + 1e-6)
+    if with_plane:
+        torch.testing.assert_close(mine[2].grad, leaves[2].grad, rtol=1e-5, atol=1e-6)
+
+
+def test_fused_encoder_matches_stock_torch_encoder(H):
+    """base_encoder with K9 (default on CUDA) vs the same module with fused_pool = False: outputs and every weight gradient."""
+    from aur_ppo_amd.base_cnns import base_encoder, weights_init
+    for shape in ((2, 128, 128), (4, 84, 84)):
+        torch.manual_seed(3)
+        enc = base_encoder(obs_shape=shape, out_dim=32).cuda()
+        enc.apply(weights_init)
+        obs = torch.rand(5, shape[0] - 1, shape[1], shape[2], device="cuda")
+        state = (torch.rand(5, device="cuda") < 0.5).float()
+        outs = []
+        for fused in (True, False):
+            enc.fused_pool = fused
+            enc.zero_grad()
+            f = enc.forward_split(obs, state)
+            (f * torch.linspace(0.5, 1.5, f.numel(), device="cuda").view_as(f)).sum().backward()
+            outs.append((f.detach().clone(), [p.grad.clone() for p in enc.parameters()]))
+        torch.testing.assert_close(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-6)
+        for a, b in zip(outs[0][1], outs[1][1]):
+            torch.testing.assert_close(a, b, rtol=2e-4, atol=1e-5 * float(b.abs().max()) + 1e-7)

@@ -10,6 +10,12 @@ import torch
 T0 = time.time()
 def note(msg):
     print(f"[bench_robot {time.time() - T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+import threading
+def _heartbeat():      # MIOpen compiles / searches its solvers on first use of a shape: minutes of silence on a fresh box
+    while True:
+        time.sleep(60)
+        note("still running")
+threading.Thread(target=_heartbeat, daemon=True).start()
 ap = argparse.ArgumentParser()
 ap.add_argument("--config", type=int, default=3, choices=(3, 5))
 ap.add_argument("--envs", type=int, default=0)
@@ -18,7 +24,9 @@ ap.add_argument("--epochs", type=int, default=4)
 ap.add_argument("--minibatches", type=int, default=4)
 ap.add_argument("--updates", type=int, default=2)
 ap.add_argument("--channels-last", action="store_true")
-ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark: let MIOpen time its solvers per shape")
+ap.add_argument("--kernel-table", action="store_true", help="after the timed updates, one more under torch.profiler: top kernels by GPU time")
+ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark: let MIOpen time its solvers per shape "
+                "(on a fresh box the search for the 8192-row minibatch shapes alone ran past 7 minutes: not used)")
 args = ap.parse_args()
 from aur_ppo_amd.robot_ppo import robot_ppo
 from aur_ppo_amd.robot_run import build_parser, params_from_args
@@ -57,6 +65,15 @@ t0 = time.perf_counter()
 for _ in range(args.updates): step()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / args.updates
+if args.kernel_table:
+    from torch.profiler import ProfilerActivity, profile
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        step(); torch.cuda.synchronize()
+    rows = sorted(prof.key_averages(), key=lambda e: -e.device_time_total)
+    tot = sum(e.device_time_total for e in rows)
+    note(f"kernel table of one steady-state update ({tot / 1e3:.1f} ms of GPU time):")
+    for e in rows[:30]:
+        print(f"  {e.device_time_total / 1e3:9.1f} ms {100 * e.device_time_total / tot:5.1f}%  x{e.count:<6d} {e.key[:120]}", file=sys.stderr)
 # forward conv FLOPs of ONE encoder per sample (2 * out_pixels * out_ch * in_ch * 9), two encoders (actor, critic), fwd + bwd ~ 3x
 def conv_flops(size, cin):
     f, c_in, s = 0, cin, size
