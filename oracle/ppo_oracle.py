@@ -544,3 +544,22 @@ def reference_ppobullet_update(pi, critic, pi_opt, v_opt, batch, next_obs, next_
         if approx_kl is not None and approx_kl > hp["target_kl"]:
             break
     return np.array(rows, dtype=np.float64), returns, advantages
+
+
+# --------------------------------------------------------------------------
+# K9's checker: the element-wise tail of a conv block of the robot policy's encoder
+# --------------------------------------------------------------------------
+def bias_relu_pool2(x, bias=None, scale=None, plane=None):
+    """``nn.MaxPool2d(2)(nn.ReLU()(conv_out))`` of src/nets/base_cnns.py:28-45 with the convolution's bias add and, for
+    the first block, the tiled gripper-state channel of src/models/robot_actor_critic.py:58-59 written as
+    ``scale[b] * plane[c,h,w]`` (convolution is linear in its input channels).  numpy fp32, association
+    ``(x + scale*plane) + bias``; an odd trailing row / column is dropped (floor), as torch's pool does."""
+    v = np.asarray(x, dtype=F32)
+    if plane is not None:
+        v = v + np.asarray(scale, dtype=F32).reshape(-1, 1, 1, 1) * np.asarray(plane, dtype=F32).reshape((1,) + v.shape[1:])
+    if bias is not None:
+        v = v + np.asarray(bias, dtype=F32).reshape(1, -1, 1, 1)
+    v = np.maximum(v, F32(0))
+    B, C, H, W = v.shape
+    v = v[:, :, :H // 2 * 2, :W // 2 * 2].reshape(B, C, H // 2, 2, W // 2, 2)
+    return v.max(axis=(3, 5))

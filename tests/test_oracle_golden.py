@@ -254,3 +254,15 @@ def test_robot_actor_critic_matches_reference_construction_and_outputs():
     for got, key in ((actions, "actions"), (unscaled, "unscaled"), (logp, "logp"), (ent, "ent"), (val, "val"),
                      (v2, "value_fn"), (u_plan, "u_plan"), (a_plan, "a_plan")):
         np.testing.assert_allclose(got.numpy(), z[key], rtol=2e-5, atol=2e-6, err_msg=key)
+
+
+def test_oracle_bias_relu_pool2_is_the_torch_op_chain():
+    """The K9 checker against the modules it restates (conv bias + nn.ReLU + nn.MaxPool2d(2), base_cnns.py:28-45)."""
+    import torch.nn.functional as Fn
+    g = torch.Generator().manual_seed(4)
+    for (B, C, H, W) in ((2, 3, 8, 8), (1, 2, 7, 9), (3, 4, 21, 21)):
+        x, b = torch.randn(B, C, H, W, generator=g), torch.randn(C, generator=g)
+        s, p = (torch.rand(B, generator=g) < 0.5).float(), torch.randn(1, C, H, W, generator=g)
+        ref = Fn.max_pool2d(Fn.relu((x + s.view(-1, 1, 1, 1) * p) + b.view(1, -1, 1, 1)), 2)
+        np.testing.assert_array_equal(O.bias_relu_pool2(x.numpy(), b.numpy(), s.numpy(), p.numpy()), ref.numpy())
+        np.testing.assert_array_equal(O.bias_relu_pool2(x.numpy(), b.numpy()), Fn.max_pool2d(Fn.relu(x + b.view(1, -1, 1, 1)), 2).numpy())
