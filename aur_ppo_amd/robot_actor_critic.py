@@ -3,8 +3,10 @@
 ``.evaluate(state, obs, action=None) -> (actions, unscaled_actions, log_prob (B,), entropy (B,), value)``,
 ``.value(state, obs)``, ``.decodeActions(*cols)``, ``.getActionFromPlan(plan)``, ``.test_action``.
 
-The equivariant branch wraps e2cnn 0.2.3 upstream (src/nets/equiv.py); e2cnn is neither vendored
-nor installed, and no reference test pins it, so it is not built here (parity unpinned -- DESIGN.md)."""
+``equivariant=True`` selects upstream's C4-equivariant actor / critic layout (src/nets/equiv.py).  Upstream builds it on
+e2cnn 0.2.3, which is neither vendored nor installed and which no reference test pins: aur_ppo_amd/equiv.py implements the
+same field layout directly (exact 90-degree filter rotations) -- BUILD-DEFINED weights, parity unpinned, equivariance
+property-tested (DESIGN.md)."""
 from __future__ import annotations
 
 import math
@@ -20,7 +22,7 @@ _HALF_LOG_2PI = 0.5 * math.log(2.0 * math.pi)
 
 class robot_actor_critic(nn.Module):
     def __init__(self, device, equivariant: bool, dx=0.02, dy=0.02, dz=0.02, dr=np.pi / 8, n_a=5, tau=0.001,
-                 obs_shape=(1, 128, 128)) -> None:
+                 obs_shape=(1, 128, 128), n_hidden=128) -> None:
         """``obs_shape`` (extra, last): (channels, H, W) of the image observation -- (1, 128, 128) upstream; (3, 84, 84)
         selects the build-defined encoder of base_cnns.base_encoder.  The gripper state adds one input plane."""
         super().__init__()
@@ -36,9 +38,11 @@ class robot_actor_critic(nn.Module):
         self.memory_format = None      # torch.channels_last: NHWC activations behind the first convolution (trainer option)
         self.equivariant = equivariant
         if equivariant:
-            raise NotImplementedError(
-                "equivariant=True needs e2cnn's C4 steerable convolutions (src/nets/equiv.py), a third-party "
-                "dependency that is not available offline and whose arithmetic no reference test pins")
+            # src/models/robot_actor_critic.py:33-35: only an actor (mean AND log-std from the network) and a critic
+            from .equiv import EquivariantActor, EquivariantCritic
+            self.actor = EquivariantActor(obs_shape=net_in, action_dim=n_a, n_hidden=n_hidden)
+            self.critic = EquivariantCritic(obs_shape=net_in, n_hidden=n_hidden)
+            return
         self.network = base_encoder(obs_shape=net_in, out_dim=128)   # unused upstream too; kept for state dicts
         self.actor = base_actor(obs_shape=net_in)
         self.actor.apply(weights_init)
@@ -49,7 +53,13 @@ class robot_actor_critic(nn.Module):
     def forward(self, act):
         pass
 
+    @staticmethod
+    def _cat(state, obs):
+        return torch.cat([obs, state.reshape(state.size(0), 1, 1, 1).to(obs.dtype).repeat(1, 1, obs.shape[2], obs.shape[3])], dim=1)
+
     def value(self, state, obs):
+        if self.equivariant:          # the tiled state is a constant plane: a trivial (rotation-invariant) input field
+            return self.critic(self._cat(state.to(self.device), obs.to(self.device)))
         # upstream tiles the gripper state to a plane and concatenates it (:58-59); folded into conv 1 here
         return self.critic(obs.to(self.device), state.to(self.device), self.memory_format)
 
@@ -78,8 +88,12 @@ class robot_actor_critic(nn.Module):
 
     def evaluate(self, state, obs, action=None):
         state, obs = state.to(self.device), obs.to(self.device)
-        mean = self.actor(obs, state, self.memory_format)
-        logstd = self.actor_logstd.expand_as(mean)
+        if self.equivariant:          # src/models/robot_actor_critic.py:109-110
+            cat_obs = self._cat(state, obs)
+            mean, logstd = self.actor(cat_obs)
+        else:
+            mean = self.actor(obs, state, self.memory_format)
+            logstd = self.actor_logstd.expand_as(mean)
         std = torch.exp(logstd)
         if action is None:
             action = mean + std * torch.randn_like(mean)            # == Normal(mean, std).rsample()
@@ -87,8 +101,13 @@ class robot_actor_critic(nn.Module):
         log_prob = (-(z * z) / (2 * std * std) - logstd - _HALF_LOG_2PI).sum(1)
         entropy = (0.5 + _HALF_LOG_2PI + logstd).sum(1)
         unscaled_actions, actions = self.decodeActions(*[action[:, i] for i in range(self.n_a)])
+        if self.equivariant:
+            return actions, unscaled_actions, log_prob, entropy, self.critic(cat_obs)
         return actions, unscaled_actions, log_prob, entropy, self.critic(obs, state, self.memory_format)
 
     def test_action(self, state, obs):
+        if self.equivariant:
+            mean = torch.tanh(self.actor(self._cat(state.to(self.device), obs.to(self.device)))[0])
+            return self.decodeActions(*[mean[:, i] for i in range(self.n_a)])
         mean = torch.tanh(self.actor(obs.to(self.device), state.to(self.device), self.memory_format))
         return self.decodeActions(*[mean[:, i] for i in range(self.n_a)])

@@ -124,8 +124,11 @@ class robot_ppo(FlatAdamMixin):
         self.plot_index = 0
         # extra, optional params: obs_size / obs_channels -- (1, 128, 128) upstream; (3, 84, 84) is BASELINE config 5's shape
         self.obs_shape = (int(params.get("obs_channels", 1)), int(params.get("obs_size", 128)), int(params.get("obs_size", 128)))
-        self.policy = robot_actor_critic(self.device, self.equivariant, obs_shape=self.obs_shape).to(self.device)
-        self.expert = robot_actor_critic(self.device, self.equivariant, obs_shape=self.obs_shape).to(self.device)
+        kw = dict(obs_shape=self.obs_shape)
+        if "equiv_hidden" in params:           # extra: width of the build-defined equivariant nets (128 regular fields upstream)
+            kw["n_hidden"] = int(params["equiv_hidden"])
+        self.policy = robot_actor_critic(self.device, self.equivariant, **kw).to(self.device)
+        self.expert = robot_actor_critic(self.device, self.equivariant, **kw).to(self.device)
         if self.device.type == "cuda" and bool(params.get("channels_last", False)):
             self.policy.memory_format = torch.channels_last      # NHWC activations from the first convolution on
         if self.world > 1:
@@ -171,10 +174,11 @@ class robot_ppo(FlatAdamMixin):
         return [("actor_state", self.policy.actor), ("critic_state", self.policy.critic)]
 
     def _checkpoint_extra(self):
-        return {"actor_logstd": self.policy.actor_logstd.detach().cpu().clone()}
+        ls = getattr(self.policy, "actor_logstd", None)       # the equivariant actor produces its own log-std
+        return {"actor_logstd": ls.detach().cpu().clone()} if ls is not None else {}
 
     def _checkpoint_restore(self, sd):
-        if "actor_logstd" in sd:
+        if "actor_logstd" in sd and hasattr(self.policy, "actor_logstd"):
             self.policy.actor_logstd.copy_(sd["actor_logstd"])
 
     # ------------------------------------------------------------------ rollout (src/robot_ppo.py:161-197)
