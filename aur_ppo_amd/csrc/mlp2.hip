@@ -46,6 +46,9 @@ namespace {
 constexpr int kThreads2 = 512;
 constexpr int kSetThreads = 256;
 constexpr int kCh = 4;       // operand prefetch depth of the MFMA chains (registers are halved at 2 waves/SIMD)
+#ifndef AURPPO_BAR_SLEEP
+#define AURPPO_BAR_SLEEP 1   // s_sleep argument of the software barriers' poll loops (A/B knob; 0 = poll back to back)
+#endif
 
 // LDS carve-up (floats).  Shared by both sets:
 constexpr int oW2 = 0;                       // [2][H][LD]
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
         if (lane == 0) (void)__hip_atomic_fetch_add(&s_bar[set], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         bar_gen += 4;
         while (__hip_atomic_load(&s_bar[set], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - bar_gen < 0)
-            __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_s_sleep(AURPPO_BAR_SLEEP);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     };
     // Between the layers of one net only that net's two waves exchange data (each writes its column half of H1 / H2 /
@@ -354,7 +357,7 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
         if (lane == 0) (void)__hip_atomic_fetch_add(&s_pbar[set][net], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         pbar_gen += 2;
         while (__hip_atomic_load(&s_pbar[set][net], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - pbar_gen < 0)
-            __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_s_sleep(AURPPO_BAR_SLEEP);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     };
     for (int it = 0; s_first[set] != 0; ++it) {

@@ -583,6 +583,10 @@ static double need_words(int n) { return expected_draws(n) + 12.0 * sqrt(2.0 * (
 // dispatcher is free to put both on the same CU, where the 16 accept waves take four issue slots in five from the
 // twist (rocprof in-situ: k_mt_fill 640 us alone, 850-910 us next to the accept kernel).  Each therefore asks for
 // more than half a CU's LDS (unused), which no two of them can get together.
+#ifndef AURPPO_ACC_WPT
+#define AURPPO_ACC_WPT 8      // draws per thread per accept step (A/B knob)
+#endif
+constexpr int kAccWpt = AURPPO_ACC_WPT;
 constexpr size_t kOwnCuLds = 81 * 1024;
 static hipError_t own_cu_setup() {
     static bool done_of[kMaxDevices] = {false};
@@ -591,7 +595,7 @@ static hipError_t own_cu_setup() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mt_fill), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)kOwnCuLds);
     if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fy_accept<1024, 8>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fy_accept<1024, kAccWpt>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kOwnCuLds);
     done = e == hipSuccess;
     return e;
@@ -634,7 +638,7 @@ int permute_once(aurppo_rng* rng, const int32_t* in, int32_t* out, int n, hipStr
         AURPPO_HIP_TRY(hipMemsetAsync(rng->d_head[h], 0xff, sizeof(int32_t) * (size_t)n, s));
         rng->head_clean[h] = n;
     }
-    hipLaunchKernelGGL((k_fy_accept<1024, 8>), dim3(1), dim3(1024), kOwnCuLds, s, rng->d_ring, (long long)rng->ring_cap,
+    hipLaunchKernelGGL((k_fy_accept<1024, kAccWpt>), dim3(1), dim3(1024), kOwnCuLds, s, rng->d_ring, (long long)rng->ring_cap,
                        rng->d_j[slot], n, rng->d_pos, 4 + slot);
     AURPPO_LAUNCH_CHECK("k_fy_accept");
     AURPPO_HIP_TRY(hipEventRecord(rng->ev_acc[slot], s));

@@ -70,3 +70,45 @@ def test_robot_train_runs_on_gpu():
     a = robot_ppo(p)
     a.train()
     assert np.isfinite(a._last_scalars).all() and a._last_scalars.shape == (8, 9)
+
+
+@pytest.mark.parametrize("C,S", [(1, 128), (3, 84)], ids=["config3_width", "config5_shard_width"])
+def test_robot_update_at_config_env_count_fused_blocks_equal_stock_blocks(C, S):
+    """BASELINE configs 3 / 5 run 256 envs per GPU: one update at that env count (T = 2, two minibatches of 256 images), once
+    with K9 in the encoder blocks and once with the stock torch ops (``fused_pool = False``), from the same weights, data
+    and shuffle seed -- the loss scalars of every step and the final weights must agree (the CPU oracle is hours away at
+    this width; at N = 8 both paths are held to it above)."""
+    from aur_ppo_amd.base_cnns import base_encoder
+    from aur_ppo_amd.robot_ppo import robot_ppo
+    from aur_ppo_amd.robot_run import build_parser, params_from_args
+    N, T = 256, 2
+    p = params_from_args(build_parser().parse_args([]))
+    p.update(gym_id="Synthetic-arm", num_envs=N, num_steps=T, total_timesteps=N * T, num_update_epochs=2, num_minibatches=2,
+             do_pretraining=False, log=False, obs_size=S, obs_channels=C)
+    outs = []
+    for fused in (True, False):
+        torch.manual_seed(4)
+        a = robot_ppo(p)
+        for m in a.policy.modules():
+            if isinstance(m, base_encoder):
+                m.fused_pool = fused
+        g = torch.Generator(device="cuda").manual_seed(6)
+        b = a.buffer
+        b.states.copy_((torch.rand(T, N, device="cuda", generator=g) < 0.5).float())
+        b.observations.copy_(torch.rand(T, N, C, S, S, device="cuda", generator=g))
+        b.actions.copy_(0.3 * torch.randn(T, N, 5, device="cuda", generator=g))
+        b.rewards.copy_((torch.rand(T, N, device="cuda", generator=g) < 0.3).float())
+        with torch.no_grad():
+            for t in range(T):
+                _, _, lp, _, v = a.policy.evaluate(b.states[t], b.observations[t], b.actions[t])
+                b.log_probs[t].copy_(lp + 0.05 * torch.randn(N, device="cuda", generator=g))
+                b.values[t].copy_(v.flatten())
+        a.seed_all(1)
+        ret, adv = a.advantages(b.states[0], b.observations[0], torch.zeros(N, device="cuda"), b, T)
+        a.update(b.flatten(ret, adv), 2, a.batch_size, a.minibatch_size, [])
+        torch.cuda.synchronize()
+        outs.append((a._last_scalars.copy(), a.bucket.flat_param.detach().cpu().clone()))
+    assert outs[0][0].shape == (4, 9) and np.isfinite(outs[0][0]).all()
+    np.testing.assert_allclose(outs[0][0][:, :6], outs[1][0][:, :6], rtol=2e-4, atol=2e-5)
+    d = (outs[0][1] - outs[1][1]).abs()
+    assert float(d.max()) <= 1.2e-3 and float((d > 3e-5).float().mean()) < 0.02, (float(d.max()), float((d > 3e-5).float().mean()))

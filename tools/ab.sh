@@ -9,7 +9,7 @@ for r in $(seq $rounds); do
     python - "$which" "$line" <<'PY'
 import json, sys
 d = json.loads(sys.argv[2]); r = d["roofline"]
-print(f"{sys.argv[1]:4s} ms_per_step {d['ms_per_step']:.4f}  probe_us {r.get('kernel_us', r.get('launch_us', 0))}  frac {r['frac']:.4f}")
+print(f"{sys.argv[1]:4s} ms_per_step {d['ms_per_step']:.4f}  probe_us {r.get('avg_launch_us', 0)}  frac {r['frac']:.4f}")
 PY
   done
 done
