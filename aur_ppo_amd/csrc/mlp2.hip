@@ -46,6 +46,10 @@ namespace {
 constexpr int kThreads2 = 512;
 constexpr int kSetThreads = 256;
 constexpr int kCh = 4;       // operand prefetch depth of the MFMA chains (registers are halved at 2 waves/SIMD)
+#ifndef AURPPO_KCH_BIG
+#define AURPPO_KCH_BIG 4     // prefetch depth of the 32- and 64-deep chains (A/B knob)
+#endif
+constexpr int kChB = AURPPO_KCH_BIG;
 #ifndef AURPPO_BAR_SLEEP
 #define AURPPO_BAR_SLEEP 1   // s_sleep argument of the software barriers' poll loops (A/B knob; 0 = poll back to back)
 #endif
@@ -403,18 +407,18 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
             f32x16 acc = zero16();
             const int ij = ln & 31, kk = ln >> 5;
             const float* Xr = sX + ij * LD + kk;
-            float av[2][kCh];
+            float av[2][kChB];
 #pragma unroll
-            for (int u = 0; u < kCh; ++u) av[0][u] = Xr[2 * u];
+            for (int u = 0; u < kChB; ++u) av[0][u] = Xr[2 * u];
 #pragma unroll
-            for (int c = 0; c < H / (2 * kCh); ++c) {
-                if (c + 1 < H / (2 * kCh)) {
+            for (int c = 0; c < H / (2 * kChB); ++c) {
+                if (c + 1 < H / (2 * kChB)) {
 #pragma unroll
-                    for (int u = 0; u < kCh; ++u) av[(c + 1) & 1][u] = Xr[2 * kCh * (c + 1) + 2 * u];
+                    for (int u = 0; u < kChB; ++u) av[(c + 1) & 1][u] = Xr[2 * kChB * (c + 1) + 2 * u];
                 }
 #pragma unroll
-                for (int u = 0; u < kCh; ++u)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c & 1][u], w1r[kCh * c + u], acc, 0, 0, 0);
+                for (int u = 0; u < kChB; ++u)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c & 1][u], w1r[kChB * c + u], acc, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
             prefetch(sIdx + ((it + 1) & 1) * R, sl);    // rows of tile it+1 (its indices are already in LDS)
@@ -430,7 +434,7 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
             f32x16 acc = zero16();
             const float* W = sW2 + (net * H + cb * 32) * LD;
             const float* Hin = sH1 + net * R * LD;
-            mma32<H, kCh, true>(acc, [&](int i, int k) { return Hin[i * LD + k]; }, [&](int k, int j) { return W[j * LD + k]; }, ln);
+            mma32<H, kChB, true>(acc, [&](int i, int k) { return Hin[i * LD + k]; }, [&](int k, int j) { return W[j * LD + k]; }, ln);
             const int col = cb * 32 + (ln & 31);
             const float bias = sB2[net * H + col];
 #pragma unroll
@@ -562,11 +566,11 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
             float* H1 = sH1 + net * R * LD;
 #pragma unroll
             for (int ob = 0; ob < 2; ++ob)
-                mma32<R, kCh, true>(gW2[ob], [&](int i, int k) { return dZ[k * LD + ob * 32 + i]; },
+                mma32<R, kChB, true>(gW2[ob], [&](int i, int k) { return dZ[k * LD + ob * 32 + i]; },
                          [&](int k, int j) { return H1[k * LD + cb * 32 + j]; }, ln);
             const float* W2 = sW2 + net * H * LD;
             f32x16 acc = zero16();
-            mma32<H, kCh, true>(acc, [&](int i, int k) { return dZ[i * LD + k]; }, [&](int k, int j) { return W2[k * LD + cb * 32 + j]; }, ln);
+            mma32<H, kChB, true>(acc, [&](int i, int k) { return dZ[i * LD + k]; }, [&](int k, int j) { return W2[k * LD + cb * 32 + j]; }, ln);
             const int col = cb * 32 + (ln & 31);
             float colsum = 0.0f;
 #pragma unroll
@@ -588,7 +592,7 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
                 const float* dZ = sH1 + net * R * LD;
 #pragma unroll
                 for (int ob = 0; ob < 2; ++ob)
-                    mma32<R, kCh, true>(gW1[ob], [&](int i, int k) { return dZ[k * LD + ob * 32 + i]; },
+                    mma32<R, kChB, true>(gW1[ob], [&](int i, int k) { return dZ[k * LD + ob * 32 + i]; },
                              [&](int k, int j) { return sX[k * LD + cb * 32 + j]; }, ln);
             }
             load_w1(w1r, ln);

@@ -49,7 +49,9 @@ struct aurppo_rng {
     size_t head_cap;     // entries per d_head buffer (max_n rounded up to whole clear chunks)
     size_t ring_cap;     // words, a multiple of 624
     hipStream_t fill_stream;   // the twist runs one shuffle ahead of its consumer on this stream; resolves follow it there
-    hipEvent_t ev_fill[2], ev_acc[2], ev_link[2], ev_res, ev_sync;
+    hipStream_t post_stream;   // AURPPO_K2_POST_STREAM=1: link + resolve run here, beside the next accept AND the next fill
+    int use_post;
+    hipEvent_t ev_fill[2], ev_acc[2], ev_link[2], ev_post[2], ev_res, ev_sync;
     long seq;            // shuffles issued since the last (re)seed
     double primed_need;  // words-per-shuffle the look-ahead fill was sized for (0: nothing in flight)
 };
@@ -633,9 +635,14 @@ int permute_once(aurppo_rng* rng, const int32_t* in, int32_t* out, int n, hipStr
     }
     AURPPO_HIP_TRY(hipStreamWaitEvent(s, rng->ev_fill[slot], 0));
     AURPPO_HIP_TRY(own_cu_setup());
+    // where link + resolve run: behind the accept on the caller's stream / the fill stream (default), or both on a third
+    // stream of the handle, so that the accept chain and the fill chain carry nothing else
+    hipStream_t ls = rng->use_post ? rng->post_stream : s;
+    if (rng->use_post && rng->seq >= 2)       // this accept overwrites the swap targets shuffle seq-2's resolve read
+        AURPPO_HIP_TRY(hipStreamWaitEvent(s, rng->ev_post[slot], 0));
     if (rng->head_clean[h] < n) {
         // first shuffle after a (re)start, or a larger n than the previous call prepared: clear here (rare path)
-        AURPPO_HIP_TRY(hipMemsetAsync(rng->d_head[h], 0xff, sizeof(int32_t) * (size_t)n, s));
+        AURPPO_HIP_TRY(hipMemsetAsync(rng->d_head[h], 0xff, sizeof(int32_t) * (size_t)n, ls));
         rng->head_clean[h] = n;
     }
     hipLaunchKernelGGL((k_fy_accept<1024, kAccWpt>), dim3(1), dim3(1024), kOwnCuLds, s, rng->d_ring, (long long)rng->ring_cap,
@@ -657,10 +664,11 @@ int permute_once(aurppo_rng* rng, const int32_t* in, int32_t* out, int n, hipStr
         const char* e = getenv("AURPPO_K2_LINK_WGS");
         link_wgs = e && *e ? atoi(e) : 48;
     }
-    hipLaunchKernelGGL(k_fy_link, dim3(link_wgs > 0 && link_wgs < grid ? link_wgs : grid), dim3(256), 0, s, rng->d_j[slot],
+    if (rng->use_post) AURPPO_HIP_TRY(hipStreamWaitEvent(ls, rng->ev_acc[slot], 0));
+    hipLaunchKernelGGL(k_fy_link, dim3(link_wgs > 0 && link_wgs < grid ? link_wgs : grid), dim3(256), 0, ls, rng->d_j[slot],
                        rng->d_head[h], rng->d_next[slot], n, rng->d_head[hn], clr_n);
     AURPPO_LAUNCH_CHECK("k_fy_link");
-    AURPPO_HIP_TRY(hipEventRecord(rng->ev_link[slot], s));
+    AURPPO_HIP_TRY(hipEventRecord(rng->ev_link[slot], ls));
     // Fill stream, in this order: the NEXT shuffle's draws (assumed the same size; ordered after the PREVIOUS accept,
     // ev_acc of the other slot, so the cursor it reads is at most one shuffle stale -- what the 2*need target
     // covers), then THIS shuffle's resolve.  The caller's stream is then free for the next accept while the resolve
@@ -675,11 +683,13 @@ int permute_once(aurppo_rng* rng, const int32_t* in, int32_t* out, int n, hipStr
         AURPPO_LAUNCH_CHECK("k_mt_fill");
         AURPPO_HIP_TRY(hipEventRecord(rng->ev_fill[slot ^ 1], rng->fill_stream));
     }
-    AURPPO_HIP_TRY(hipStreamWaitEvent(rng->fill_stream, rng->ev_link[slot], 0));
-    hipLaunchKernelGGL(k_fy_resolve, dim3(grid), dim3(256), 0, rng->fill_stream, rng->d_j[slot], rng->d_head[h],
+    hipStream_t rs = rng->use_post ? rng->post_stream : rng->fill_stream;
+    if (!rng->use_post) AURPPO_HIP_TRY(hipStreamWaitEvent(rs, rng->ev_link[slot], 0));
+    hipLaunchKernelGGL(k_fy_resolve, dim3(grid), dim3(256), 0, rs, rng->d_j[slot], rng->d_head[h],
                        rng->d_next[slot], in, out, n);
     AURPPO_LAUNCH_CHECK("k_fy_resolve");
-    AURPPO_HIP_TRY(hipEventRecord(rng->ev_res, rng->fill_stream));
+    AURPPO_HIP_TRY(hipEventRecord(rng->ev_res, rs));
+    if (rng->use_post) AURPPO_HIP_TRY(hipEventRecord(rng->ev_post[slot], rs));
     rng->seq += 1;
     return AURPPO_OK;
 }
@@ -693,6 +703,7 @@ static int join_resolves(aurppo_rng* rng, hipStream_t s) {
 // Drain the look-ahead and restart the stream at d_state (after seed / set_state wrote it on `s`).
 static int restart_stream(aurppo_rng* rng, hipStream_t s) {
     AURPPO_HIP_TRY(hipStreamSynchronize(rng->fill_stream));
+    if (rng->post_stream) AURPPO_HIP_TRY(hipStreamSynchronize(rng->post_stream));
     hipLaunchKernelGGL(k_mt_origin, dim3(1), dim3(kFillThreads), 0, s, rng->d_state, rng->d_last, rng->d_ring,
                        (long long)rng->ring_cap, rng->d_pos);
     AURPPO_LAUNCH_CHECK("k_mt_origin");
@@ -732,11 +743,15 @@ extern "C" int aurppo_mt19937_create(aurppo_rng** out, uint32_t seed, int max_n,
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
         e = hipStreamCreateWithPriority(&r->fill_stream, hipStreamNonBlocking, hi);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&r->post_stream, hipStreamNonBlocking, hi);
+        const char* pe = getenv("AURPPO_K2_POST_STREAM");
+        r->use_post = (pe && *pe == '1') ? 1 : 0;
     }
     for (int k = 0; k < 2 && e == hipSuccess; ++k) {
         e = hipEventCreateWithFlags(&r->ev_fill[k], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&r->ev_acc[k], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&r->ev_link[k], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&r->ev_post[k], hipEventDisableTiming);
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&r->ev_res, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&r->ev_sync, hipEventDisableTiming);
@@ -752,6 +767,7 @@ extern "C" int aurppo_mt19937_create(aurppo_rng** out, uint32_t seed, int max_n,
 extern "C" int aurppo_mt19937_destroy(aurppo_rng* rng) {
     if (!rng) return AURPPO_OK;
     if (rng->fill_stream) (void)hipStreamSynchronize(rng->fill_stream);
+    if (rng->post_stream) (void)hipStreamSynchronize(rng->post_stream);
     (void)hipFree(rng->d_state);
     (void)hipFree(rng->d_last);
     (void)hipFree(rng->d_ring);
@@ -767,10 +783,12 @@ extern "C" int aurppo_mt19937_destroy(aurppo_rng* rng) {
         if (rng->ev_fill[k]) (void)hipEventDestroy(rng->ev_fill[k]);
         if (rng->ev_acc[k]) (void)hipEventDestroy(rng->ev_acc[k]);
         if (rng->ev_link[k]) (void)hipEventDestroy(rng->ev_link[k]);
+        if (rng->ev_post[k]) (void)hipEventDestroy(rng->ev_post[k]);
     }
     if (rng->ev_res) (void)hipEventDestroy(rng->ev_res);
     if (rng->ev_sync) (void)hipEventDestroy(rng->ev_sync);
     if (rng->fill_stream) (void)hipStreamDestroy(rng->fill_stream);
+    if (rng->post_stream) (void)hipStreamDestroy(rng->post_stream);
     delete rng;
     return AURPPO_OK;
 }
@@ -778,6 +796,7 @@ extern "C" int aurppo_mt19937_destroy(aurppo_rng* rng) {
 extern "C" int aurppo_mt19937_seed(aurppo_rng* rng, uint32_t seed, void* stream) {
     AURPPO_REQUIRE(rng, AURPPO_EINVAL, "aurppo_mt19937_seed: null handle");
     AURPPO_HIP_TRY(hipStreamSynchronize(rng->fill_stream));   // nothing may still be appending to the ring
+    if (rng->post_stream) AURPPO_HIP_TRY(hipStreamSynchronize(rng->post_stream));
     hipLaunchKernelGGL(k_mt_seed, dim3(1), dim3(64), 0, (hipStream_t)stream, rng->d_state, seed);
     AURPPO_LAUNCH_CHECK("k_mt_seed");
     return restart_stream(rng, (hipStream_t)stream);
@@ -793,6 +812,7 @@ extern "C" int aurppo_mt19937_get_state(aurppo_rng* rng, uint32_t* key_h, int32_
     AURPPO_REQUIRE(rng && key_h && pos_h, AURPPO_EINVAL, "aurppo_mt19937_get_state: null pointer");
     hipStream_t s = (hipStream_t)stream;
     AURPPO_HIP_TRY(hipStreamSynchronize(rng->fill_stream));
+    if (rng->post_stream) AURPPO_HIP_TRY(hipStreamSynchronize(rng->post_stream));
     hipLaunchKernelGGL(k_state_at_cursor, dim3(1), dim3(kFillThreads), 0, s, rng->d_state, rng->d_ring,
                        (long long)rng->ring_cap, rng->d_pos, reinterpret_cast<uint32_t*>(rng->d_meta));
     AURPPO_LAUNCH_CHECK("k_state_at_cursor");
@@ -816,6 +836,7 @@ extern "C" int aurppo_mt19937_set_state(aurppo_rng* rng, const uint32_t* key_h, 
     for (int i = 0; i < kMtN; ++i) buf[i] = key_h[i];
     buf[kMtN] = (uint32_t)pos_h;
     AURPPO_HIP_TRY(hipStreamSynchronize(rng->fill_stream));
+    if (rng->post_stream) AURPPO_HIP_TRY(hipStreamSynchronize(rng->post_stream));
     AURPPO_HIP_TRY(hipStreamSynchronize(s));   // in-flight shuffles still read the old stream
     AURPPO_HIP_TRY(hipMemcpyAsync(rng->d_state, buf, sizeof(buf), hipMemcpyHostToDevice, s));
     AURPPO_HIP_TRY(hipStreamSynchronize(s));   // buf is a stack temporary

@@ -38,7 +38,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 MFMA peak (same guide, matrix cores 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--num-steps", type=int, default=128)
@@ -256,6 +256,11 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
+    # stdout carries exactly ONE line, the JSON: anything a library prints there (RCCL announces its version on stdout when
+    # the first communicator is built) goes to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     from aur_ppo_amd import dist as D
     # AURPPO_BENCH_REHEARSE=1: every rank on cuda:0 over gloo -- a rehearsal of the N > 1 code path on a one-GPU box
     # (its timings mean nothing); the driver's runs use one device per rank over RCCL
@@ -299,9 +304,10 @@ def main():
         returns, advantages = agent.advantages(next_obs, next_done)
         agent.update(returns, advantages)
         step_no[0] += 1
-        if probe.on and not args.no_probe and step_no[0] % 4 == 1:
-            # The update replays as a hipGraph, whose kernels cannot carry readable events: every 4th
-            # step, time ONE extra stand-alone launch of the dominant kernel on the update's own inputs.
+        if probe.on and not args.no_probe and step_no[0] % 10 == 1:
+            # The update replays as a hipGraph, whose kernels cannot carry readable events: every 10th
+            # step, time ONE extra stand-alone launch of the dominant kernel on the update's own inputs
+            # (it sits inside the timed region: 150 us per ten 2.7 ms steps).
             if agent._mlp is not None:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 agent.probe_mlp_step(ev)       # events recorded inside the library, around k_mlp_step only
@@ -396,7 +402,7 @@ def main():
                     "flops_per_launch": flops, "avg_launch_us": round(ms * 1e3, 2), "launches_timed": len(mlp_events),
                     "algorithmic_hbm_bytes_per_launch": M * (4 * (Dm + A + 4) + 4),
                     "how": "hipEvent pair recorded inside the library around the K7 kernel, one extra stand-alone "
-                           "launch every 4th step on the update's own minibatch"
+                           "launch every 10th step on the update's own minibatch"
                            + (" (the update itself is a hipGraph)" if agent._graph is not None else "")}
     elif probe.pairs:
         gather_bytes = M * (8 * Dm + 8 * A + 36)          # idx + 6 streams read + written
@@ -406,7 +412,7 @@ def main():
                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc("gather_pmc.json"),
                     "bytes_per_launch": gather_bytes, "avg_launch_us": round(g_ms * 1e3, 2),
                     "launches_timed": len(probe.pairs),
-                    "how": "HIP-event pairs around one stand-alone launch every 4th step of the update's own gather"}
+                    "how": "HIP-event pairs around one stand-alone launch every 10th step of the update's own gather"}
     if roofline is not None:
         roofline["hbm_8d"] = hbm_8d
         roofline["side_stream"] = side_stream
@@ -434,7 +440,8 @@ def main():
         out["cpu_baseline"] = None
     out["parity_checked"] = bool(parity["ok"]) if parity is not None else False
     out["parity"] = parity if parity is not None else "not run (needs the N=1 cpu_baseline leg)"
-    print(json.dumps(out), flush=True)
+    sys.stdout.flush()
+    os.write(json_fd, (json.dumps(out) + "\n").encode())
     D.shutdown()
     if parity is not None and not parity["ok"]:
         sys.exit("bench.py: the GPU's first update does NOT match the oracle's -- see \"parity\" in the line above")

@@ -24,6 +24,8 @@ ap.add_argument("--epochs", type=int, default=4)
 ap.add_argument("--minibatches", type=int, default=4)
 ap.add_argument("--updates", type=int, default=2)
 ap.add_argument("--channels-last", action="store_true")
+ap.add_argument("--equivariant", action="store_true", help="the build-defined C4-equivariant actor / critic (aur_ppo_amd/equiv.py)")
+ap.add_argument("--equiv-hidden", type=int, default=128)
 ap.add_argument("--kernel-table", action="store_true", help="after the timed updates, one more under torch.profiler: top kernels by GPU time")
 ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark: let MIOpen time its solvers per shape "
                 "(on a fresh box the search for the 8192-row minibatch shapes alone ran past 7 minutes: not used)")
@@ -37,7 +39,8 @@ E = args.epochs
 torch.backends.cudnn.benchmark = bool(args.miopen_find)
 p = params_from_args(build_parser().parse_args([]))
 p.update(gym_id="Synthetic-arm", num_envs=N, num_steps=T, total_timesteps=N * T * 4, num_update_epochs=E, num_minibatches=args.minibatches,
-         do_pretraining=False, log=False, obs_size=S, obs_channels=C, channels_last=args.channels_last)
+         do_pretraining=False, log=False, obs_size=S, obs_channels=C, channels_last=args.channels_last,
+         equivariant=args.equivariant, equiv_hidden=args.equiv_hidden)
 torch.manual_seed(1)
 a = robot_ppo(p)
 note("trainer built")
@@ -84,8 +87,22 @@ def conv_flops(size, cin):
     else:
         s -= 2; f += 2 * s * s * 256 * 128 * 9; s -= 2; f += 2 * s * s * 128 * 256 * 9
     return f
-flops = 3 * 2 * conv_flops(S, C + 1) * N * T * E
-print(json.dumps({"workload": f"robot_ppo CNN policy, config {args.config}: N={N} T={T} obs=({C},{S},{S}) E={E}, {args.minibatches} minibatches of {a.minibatch_size}",
+def equiv_flops(size, cin, n):      # expanded C4 filter banks: 4 channels per regular field
+    if size == 128:
+        spec = [(cin, n // 8 * 4, 1, 2), (n // 8 * 4, n // 4 * 4, 1, 2), (n // 4 * 4, n // 2 * 4, 1, 2), (n // 2 * 4, n * 4, 1, 2),
+                (n * 4, 2 * n * 4, 1, 0), (2 * n * 4, n * 4, 0, 2), (n * 4, n * 4, 0, 0)]
+    else:
+        spec = [(cin, n // 8 * 4, 1, 2), (n // 8 * 4, n // 4 * 4, 1, 2), (n // 4 * 4, n // 2 * 4, 1, 3), (n // 2 * 4, n * 4, 0, 0),
+                (n * 4, n * 4, 0, 0), (n * 4, n * 4, 0, 0)]
+    f, s = 0, size
+    for ci, co, pad, pool in spec:
+        s = s if pad else s - 2
+        f += 2 * s * s * co * ci * 9
+        s = s // pool if pool else s
+    return f
+flops = 3 * 2 * (equiv_flops(S, C + 1, args.equiv_hidden) if args.equivariant else conv_flops(S, C + 1)) * N * T * E
+print(json.dumps({"policy": "C4-equivariant (build-defined)" if args.equivariant else "plain CNN",
+                  "workload": f"robot_ppo, config {args.config}: N={N} T={T} obs=({C},{S},{S}) E={E}, {args.minibatches} minibatches of {a.minibatch_size}",
                   "channels_last": args.channels_last, "miopen_find": args.miopen_find, "ms_per_update": round(dt * 1e3, 1),
                   "env_steps_per_s": round(N * T / dt, 1), "conv_tflop_per_update": round(flops / 1e12, 1),
                   "conv_bound_ms_at_157_tflops": round(flops / 157.3e12 * 1e3, 1),
