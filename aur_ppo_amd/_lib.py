@@ -16,6 +16,7 @@ SYMBOLS = (
     "aurppo_clip_workspace_bytes", "aurppo_grad_norm_clip_f32", "aurppo_mlp_workspace_bytes", "aurppo_mlp_ppo_step_f32",
     "aurppo_mlp_ppo_step_ev_f32", "aurppo_mlp_ppo_minibatch_f32", "aurppo_mlp_ppo_grad_f32", "aurppo_mlp_ppo_apply_f32", "aurppo_pack_records_f32", "aurppo_mlp_act_f32", "aurppo_clip_adam_f32",
     "aurppo_bias_relu_pool2_fwd_f32", "aurppo_bias_relu_pool2_bwd_f32", "aurppo_weighted_batch_sum_f32",
+    "aurppo_first_block_fwd_f32", "aurppo_first_block_bwd_f32",
 )
 
 _lib = None
@@ -73,6 +74,8 @@ def load() -> C.CDLL:
     lib.aurppo_bias_relu_pool2_fwd_f32.argtypes = [vp] * 6 + [i32] * 4 + [vp]
     lib.aurppo_bias_relu_pool2_bwd_f32.argtypes = [vp] * 4 + [i32] * 4 + [vp]
     lib.aurppo_weighted_batch_sum_f32.argtypes = [vp, vp, vp, i32, C.c_int64, vp]
+    lib.aurppo_first_block_fwd_f32.argtypes = [vp] * 6 + [i32] * 5 + [vp]
+    lib.aurppo_first_block_bwd_f32.argtypes = [vp] * 6 + [i32] * 5 + [vp]
     lib.aurppo_clip_workspace_bytes.argtypes = [C.c_int64]
     lib.aurppo_clip_workspace_bytes.restype = C.c_size_t
     lib.aurppo_grad_norm_clip_f32.argtypes = [vp, C.c_int64, f64, vp, vp, vp]

@@ -46,6 +46,7 @@ class base_encoder(nn.Module):
         self.conv = nn.Sequential(*mods)
 
     fused_pool = True      # K9 on CUDA tensors (False: the stock torch ops everywhere, for A/B runs)
+    fused_first = True     # K10 for the first block when it runs in split form on CUDA tensors
 
     def _blocks(self, x, start, scale=None, plane=None, first_weight=None):
         """Run self.conv[start:] on x; on the GPU every (Conv2d, ReLU, MaxPool2d(2)) triple becomes convolution without bias
@@ -79,6 +80,13 @@ class base_encoder(nn.Module):
         plane contributes ``state * conv(ones)`` -- one tiny per-call map -- to the first layer."""
         first = self.conv[0]
         c = obs.shape[1]
+        mods = self.conv
+        if (self.fused_first and self.fused_pool and obs.is_cuda and memory_format is None and c <= 3 and first.out_channels % 16 == 0
+                and first.kernel_size == (3, 3) and first.padding == (1, 1) and first.stride == (1, 1)
+                and isinstance(mods[1], nn.ReLU) and isinstance(mods[2], nn.MaxPool2d) and mods[2].kernel_size in (2, (2, 2))):
+            # K10: convolution of the image channels and of the tiled state, bias, ReLU and the pool in one kernel
+            from . import hip_ops as H
+            return self._blocks(H.first_block(obs, state, first.weight, first.bias), 3)
         if self.fused_pool and obs.is_cuda and memory_format is None:
             # K9 adds state * plane and the bias while it applies ReLU and the pool: the block's output is written once
             ones = torch.ones((1, 1) + tuple(obs.shape[2:]), device=obs.device, dtype=obs.dtype)

@@ -13,6 +13,8 @@
 //
 // torch semantics kept: max-pool takes the FIRST maximum of a window in row-major scan order (ties); ReLU passes no
 // gradient at x <= 0; an odd trailing row / column is dropped by the pool (floor) and gets a zero gradient.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -205,5 +207,203 @@ extern "C" int aurppo_weighted_batch_sum_f32(const float* x, const float* w, flo
     hipLaunchKernelGGL(k_weighted_batch_sum, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, w, out,
                        B, (long long)K);
     AURPPO_LAUNCH_CHECK("k_weighted_batch_sum");
+    return AURPPO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// K10: the FIRST block of the encoder in one kernel -- 3x3 convolution (padding 1) of the image channels and of the tiled
+// gripper-state plane, bias, ReLU, 2x2 max-pool -- forward, and its backward straight to the weight / bias gradients.
+// (src/nets/base_cnns.py:28-31 with the input of src/models/robot_actor_critic.py:58-59,106-107.)
+//
+// Why this block: its output before the pool is the largest tensor of the network (8192 x 16 x 128 x 128 floats = 8.6 GB
+// per minibatch and net) and its convolution has 1-3 input channels -- MIOpen writes those 8.6 GB, K9 reads them back, and
+// in backward K9 writes a gradient of that size which the weight-gradient kernel and the plane reduction read again.
+// Here the forward reads the observation (64 KB per sample) and writes the pooled block (262 KB + 64 KB of masks); the
+// backward reads the pooled gradient, the masks and the observation and leaves per-workgroup partial sums of dW / db --
+// the full-resolution tensors never exist.  Arithmetic: 36 FMAs per pooled element and channel, on the VALU (a 1-3 channel
+// convolution is no matrix product worth an MFMA tile); weights come through scalar loads (uniform per workgroup).
+//
+// Semantics are those of conv2d(cat[obs, state plane]) + bias -> ReLU -> MaxPool2d(2): first maximum in scan order, nothing
+// through x <= 0.  The input needs no gradient (it is data), so the backward is complete with dW, db.
+namespace {
+
+constexpr int kFbThreads = 256;
+constexpr int kFbCo = 16;      // output channels per workgroup (the plain encoder's first block has 16; wider ones loop groups)
+
+// wave-wide sum with DPP moves (no LDS traffic): quads, row halves, rows, then the four row sums through readlane
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    auto mv = [](float x, auto ctrl) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xf, 0xf, true)); };
+    v += mv(v, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
+    v += mv(v, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
+    v += mv(v, std::integral_constant<int, 0x141>{});   // row_half_mirror
+    v += mv(v, std::integral_constant<int, 0x140>{});   // row_mirror: every lane now holds its row's sum
+    const int iv = __float_as_int(v);
+    return (__int_as_float(__builtin_amdgcn_readlane(iv, 0)) + __int_as_float(__builtin_amdgcn_readlane(iv, 16))) +
+           (__int_as_float(__builtin_amdgcn_readlane(iv, 32)) + __int_as_float(__builtin_amdgcn_readlane(iv, 48)));
+}
+
+// grid: (ceil(Ho*Wo / 256), Co / 16, B).  A thread owns one pooled element for 16 output channels.
+template <int CI>
+__global__ __launch_bounds__(kFbThreads) void k_first_block_fwd(const float* __restrict__ obs, const float* __restrict__ w,
+                                                                const float* __restrict__ bias,
+                                                                const float* __restrict__ state, float* __restrict__ y,
+                                                                uint8_t* __restrict__ mask, int Co, int H, int W) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    const int q = blockIdx.x * kFbThreads + threadIdx.x;
+    const int cg = blockIdx.y, b = blockIdx.z;
+    const bool live = q < Ho * Wo;
+    const int ho = live ? q / Wo : 0, wo = live ? q - ho * Wo : 0;
+    const float sv = state[b];
+    // the 4x4 input patch of this pooled cell, per image channel (rows 2ho-1 .. 2ho+2, cols 2wo-1 .. 2wo+2), zero outside
+    float p[CI][4][4];
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci) {
+        const float* op = obs + ((size_t)b * CI + ci) * H * W;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int h = 2 * ho - 1 + r;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int ww = 2 * wo - 1 + c;
+                const bool in = live && h >= 0 && h < H && ww >= 0 && ww < W;
+                p[ci][r][c] = in ? op[(size_t)(in ? h : 0) * W + (in ? ww : 0)] : 0.0f;
+            }
+        }
+    }
+    // border classes of the four conv positions (rows 2ho, 2ho+1; cols 2wo, 2wo+1) as 0/1 factors: the state plane's
+    // response is the sum of the channel's state taps that fall inside the image = all - border row - border column + corner
+    const float ft = ho == 0 ? 1.0f : 0.0f, fb = 2 * ho + 1 == H - 1 ? 1.0f : 0.0f;
+    const float fl = wo == 0 ? 1.0f : 0.0f, fr = 2 * wo + 1 == W - 1 ? 1.0f : 0.0f;
+    for (int cc = 0; cc < kFbCo; ++cc) {
+        const int c = cg * kFbCo + cc;
+        const float* wc = w + (size_t)c * (CI + 1) * 9;       // uniform address: scalar loads
+        float acc[4];
+        const float bv = bias ? bias[c] : 0.0f;
+        const float* ts = wc + CI * 9;
+        // state plane first, then the bias (the association of base_encoder.forward_split: (conv + state*plane) + bias)
+        const float all = ((ts[0] + ts[1]) + (ts[2] + ts[3])) + ((ts[4] + ts[5]) + (ts[6] + ts[7])) + ts[8];
+        const float r0 = ts[0] + ts[1] + ts[2], r2 = ts[6] + ts[7] + ts[8];
+        const float c0 = ts[0] + ts[3] + ts[6], c2 = ts[2] + ts[5] + ts[8];
+        const float pl[4] = {all - ft * r0 - fl * c0 + ft * fl * ts[0], all - ft * r0 - fr * c2 + ft * fr * ts[2],
+                             all - fb * r2 - fl * c0 + fb * fl * ts[6], all - fb * r2 - fr * c2 + fb * fr * ts[8]};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = 0.0f;
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const float wv = wc[ci * 9 + kh * 3 + kw];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc[u] = fmaf(p[ci][(u >> 1) + kh][(u & 1) + kw], wv, acc[u]);
+                }
+        float m = 0.0f;
+        int k = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float v = (acc[u] + sv * pl[u]) + bv;
+            if (u == 0 || v > m) { m = v; k = u; }
+        }
+        const bool alive = m > 0.0f;
+        if (live) {
+            const size_t o = (((size_t)b * Co + c) * Ho + ho) * Wo + wo;
+            y[o] = alive ? m : 0.0f;
+            mask[o] = alive ? (uint8_t)k : (uint8_t)4;
+        }
+    }
+}
+
+// grid: (1, Co / 16, B): one workgroup per sample and channel group walks all pooled elements and leaves
+// dw_part[(b * Co/16 + cg)][16][(CI+1)*9] and db_part[...][16].
+template <int CI>
+__global__ __launch_bounds__(kFbThreads) void k_first_block_bwd(const float* __restrict__ dy, const uint8_t* __restrict__ mask,
+                                                                const float* __restrict__ obs,
+                                                                const float* __restrict__ state,
+                                                                float* __restrict__ dw_part, float* __restrict__ db_part,
+                                                                int Co, int H, int W) {
+    constexpr int NT = (CI + 1) * 9;
+    __shared__ float s_red[kFbThreads / kWave][NT + 1];
+    const int Ho = H >> 1, Wo = W >> 1;
+    const int cg = blockIdx.y, b = blockIdx.z;
+    const float sv = state[b];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    for (int cc = 0; cc < kFbCo; ++cc) {
+        const int c = cg * kFbCo + cc;
+        const float* gp = dy + ((size_t)b * Co + c) * Ho * Wo;
+        const uint8_t* mp = mask + ((size_t)b * Co + c) * Ho * Wo;
+        float a[NT + 1];
+#pragma unroll
+        for (int t = 0; t <= NT; ++t) a[t] = 0.0f;
+        for (int q = threadIdx.x; q < Ho * Wo; q += kFbThreads) {
+            const int mk = mp[q];
+            if (mk >= 4) continue;
+            const float g = gp[q];
+            const int ho = q / Wo, wo = q - ho * Wo;
+            const int h = 2 * ho + (mk >> 1), ww = 2 * wo + (mk & 1);      // where the maximum sat
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const int hh = h + kh - 1;
+                const bool rv = hh >= 0 && hh < H;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int wx = ww + kw - 1;
+                    const bool in = rv && wx >= 0 && wx < W;
+#pragma unroll
+                    for (int ci = 0; ci < CI; ++ci) {
+                        const float x = in ? obs[(((size_t)b * CI + ci) * H + (in ? hh : 0)) * W + (in ? wx : 0)] : 0.0f;
+                        a[ci * 9 + kh * 3 + kw] = fmaf(g, x, a[ci * 9 + kh * 3 + kw]);
+                    }
+                    a[CI * 9 + kh * 3 + kw] += in ? g * sv : 0.0f;
+                }
+            }
+            a[NT] += g;
+        }
+        // 256 threads -> one value each (fixed order: deterministic)
+#pragma unroll
+        for (int t = 0; t <= NT; ++t) {
+            const float v = wave_sum_dpp(a[t]);
+            if (lane == 0) s_red[wave][t] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x <= NT) {
+            float v = 0.0f;
+#pragma unroll
+            for (int wv = 0; wv < kFbThreads / kWave; ++wv) v += s_red[wv][threadIdx.x];
+            const size_t g_ = (size_t)b * gridDim.y + cg;
+            if (threadIdx.x < NT) dw_part[(g_ * kFbCo + cc) * NT + threadIdx.x] = v;
+            else db_part[g_ * kFbCo + cc] = v;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+extern "C" int aurppo_first_block_fwd_f32(const float* obs, const float* w, const float* bias, const float* state, float* y,
+                                          uint8_t* mask, int B, int Ci, int Co, int H, int W, void* stream) {
+    AURPPO_REQUIRE(obs && w && state && y && mask, AURPPO_EINVAL, "aurppo_first_block_fwd_f32: null pointer");
+    AURPPO_REQUIRE(B > 0 && B <= 65535 && Ci >= 1 && Ci <= 3 && Co > 0 && Co % kFbCo == 0 && Co / kFbCo <= 65535 && H >= 2 && W >= 2,
+                   AURPPO_ESHAPE, "aurppo_first_block_fwd_f32: B=%d Ci=%d Co=%d H=%d W=%d (Ci in 1..3, Co a multiple of 16)", B, Ci, Co, H, W);
+    const dim3 grid(((H / 2) * (W / 2) + kFbThreads - 1) / kFbThreads, Co / kFbCo, B);
+    hipStream_t s = (hipStream_t)stream;
+    if (Ci == 1) hipLaunchKernelGGL(k_first_block_fwd<1>, grid, dim3(kFbThreads), 0, s, obs, w, bias, state, y, mask, Co, H, W);
+    else if (Ci == 2) hipLaunchKernelGGL(k_first_block_fwd<2>, grid, dim3(kFbThreads), 0, s, obs, w, bias, state, y, mask, Co, H, W);
+    else hipLaunchKernelGGL(k_first_block_fwd<3>, grid, dim3(kFbThreads), 0, s, obs, w, bias, state, y, mask, Co, H, W);
+    AURPPO_LAUNCH_CHECK("k_first_block_fwd");
+    return AURPPO_OK;
+}
+
+extern "C" int aurppo_first_block_bwd_f32(const float* dy, const uint8_t* mask, const float* obs, const float* state,
+                                          float* dw_part, float* db_part, int B, int Ci, int Co, int H, int W, void* stream) {
+    AURPPO_REQUIRE(dy && mask && obs && state && dw_part && db_part, AURPPO_EINVAL, "aurppo_first_block_bwd_f32: null pointer");
+    AURPPO_REQUIRE(B > 0 && B <= 65535 && Ci >= 1 && Ci <= 3 && Co > 0 && Co % kFbCo == 0 && Co / kFbCo <= 65535 && H >= 2 && W >= 2,
+                   AURPPO_ESHAPE, "aurppo_first_block_bwd_f32: B=%d Ci=%d Co=%d H=%d W=%d", B, Ci, Co, H, W);
+    const dim3 grid(1, Co / kFbCo, B);
+    hipStream_t s = (hipStream_t)stream;
+    if (Ci == 1) hipLaunchKernelGGL(k_first_block_bwd<1>, grid, dim3(kFbThreads), 0, s, dy, mask, obs, state, dw_part, db_part, Co, H, W);
+    else if (Ci == 2) hipLaunchKernelGGL(k_first_block_bwd<2>, grid, dim3(kFbThreads), 0, s, dy, mask, obs, state, dw_part, db_part, Co, H, W);
+    else hipLaunchKernelGGL(k_first_block_bwd<3>, grid, dim3(kFbThreads), 0, s, dy, mask, obs, state, dw_part, db_part, Co, H, W);
+    AURPPO_LAUNCH_CHECK("k_first_block_bwd");
     return AURPPO_OK;
 }

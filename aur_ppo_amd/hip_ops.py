@@ -540,3 +540,46 @@ def bias_relu_pool2(x, bias=None, scale=None, plane=None):
     convolution block of src/nets/base_cnns.py:28-45; ``scale`` / ``plane`` carry the tiled gripper-state channel of
     src/models/robot_actor_critic.py:58-59 (no gradient flows to ``scale``, the state is an input)."""
     return _BiasReluPool2.apply(x, bias, scale, plane)
+
+
+# ------------------------------------------------------------------ K10
+class _FirstBlock(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, obs, state, weight, bias):
+        lib = _lib_or_raise()
+        obs = obs.detach().contiguous()
+        state = state.detach().reshape(-1).to(torch.float32).contiguous()
+        B, Ci, Hh, Ww = obs.shape
+        Co = weight.shape[0]
+        w = weight.detach().contiguous()
+        y = torch.empty((B, Co, Hh // 2, Ww // 2), dtype=torch.float32, device=obs.device)
+        mask = torch.empty((B, Co, Hh // 2, Ww // 2), dtype=torch.uint8, device=obs.device)
+        _check(lib.aurppo_first_block_fwd_f32(_ptr(obs), _ptr(w), _optr(bias.detach().contiguous() if bias is not None else None),
+                                              _ptr(state), _ptr(y), C.c_void_p(mask.data_ptr()), B, Ci, Co, Hh, Ww, _stream()),
+               "aurppo_first_block_fwd_f32")
+        ctx.save_for_backward(obs, state, mask)
+        ctx.dims = (B, Ci, Co, Hh, Ww, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib_or_raise()
+        obs, state, mask = ctx.saved_tensors
+        B, Ci, Co, Hh, Ww, has_bias = ctx.dims
+        G = B * (Co // 16)
+        dw_part = torch.empty((G, 16, (Ci + 1) * 9), dtype=torch.float32, device=dy.device)
+        db_part = torch.empty((G, 16), dtype=torch.float32, device=dy.device)
+        _check(lib.aurppo_first_block_bwd_f32(_ptr(dy.contiguous()), C.c_void_p(mask.data_ptr()), _ptr(obs), _ptr(state),
+                                              _ptr(dw_part), _ptr(db_part), B, Ci, Co, Hh, Ww, _stream()),
+               "aurppo_first_block_bwd_f32")
+        # (B, Co/16, 16, taps) -> sum over the samples -> (Co, Ci+1, 3, 3)
+        dw = dw_part.view(B, Co // 16, 16, (Ci + 1) * 9).sum(0).reshape(Co, Ci + 1, 3, 3)
+        db = db_part.view(B, Co // 16, 16).sum(0).reshape(Co) if has_bias else None
+        return None, None, dw, db
+
+
+def first_block(obs, state, weight, bias):
+    """K10: ``max_pool2d(relu(conv2d(cat[obs, state tiled to a plane], weight, bias, padding=1)), 2)`` -- the first block of
+    src/nets/base_cnns.py:28-31 on the input of src/models/robot_actor_critic.py:58-59 -- forward and backward without the
+    full-resolution tensors.  ``weight``: (Co, Ci + 1, 3, 3), state plane last; Ci in 1..3, Co a multiple of 16."""
+    return _FirstBlock.apply(obs, state, weight, bias)

@@ -267,6 +267,19 @@ int aurppo_bias_relu_pool2_bwd_f32(const float* dy, const uint8_t* mask, float* 
                                    int H, int W, void* stream);
 int aurppo_weighted_batch_sum_f32(const float* x, const float* w, float* out, int B, int64_t K, void* stream);
 
+/* ---- K10: the encoder's first block in one kernel ----------------------------------------------------------------
+ * conv2d(cat[obs, tiled state], W, bias, padding 1) -> ReLU -> MaxPool2d(2) of src/nets/base_cnns.py:28-31 on the input
+ * of src/models/robot_actor_critic.py:58-59,106-107, without the full-resolution tensors: forward reads obs (B,Ci,H,W),
+ * Ci in 1..3, W (Co, Ci+1, 3, 3) whose LAST input channel is the state plane, bias (Co, may be NULL), state (B) and
+ * writes y, mask (B,Co,H/2,W/2) with K9's conventions.  Backward leaves, per (sample, group of 16 output channels),
+ * partial sums dw_part (B*Co/16, 16, (Ci+1)*9) and db_part (B*Co/16, 16): summed over the first dimension and laid out
+ * per channel they are the gradients of W (Co, Ci+1, 3, 3) and bias.  The input takes no gradient (it is data).  Co must
+ * be a multiple of 16. */
+int aurppo_first_block_fwd_f32(const float* obs, const float* w, const float* bias, const float* state, float* y,
+                               uint8_t* mask, int B, int Ci, int Co, int H, int W, void* stream);
+int aurppo_first_block_bwd_f32(const float* dy, const uint8_t* mask, const float* obs, const float* state,
+                               float* dw_part, float* db_part, int B, int Ci, int Co, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -420,12 +420,40 @@ def test_fused_encoder_matches_stock_torch_encoder(H):
         obs = torch.rand(5, shape[0] - 1, shape[1], shape[2], device="cuda")
         state = (torch.rand(5, device="cuda") < 0.5).float()
         outs = []
-        for fused in (True, False):
-            enc.fused_pool = fused
+        for fused, first in ((True, True), (True, False), (False, False)):
+            enc.fused_pool, enc.fused_first = fused, first
             enc.zero_grad()
             f = enc.forward_split(obs, state)
             (f * torch.linspace(0.5, 1.5, f.numel(), device="cuda").view_as(f)).sum().backward()
             outs.append((f.detach().clone(), [p.grad.clone() for p in enc.parameters()]))
-        torch.testing.assert_close(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-6)
-        for a, b in zip(outs[0][1], outs[1][1]):
-            torch.testing.assert_close(a, b, rtol=2e-4, atol=1e-5 * float(b.abs().max()) + 1e-7)
+        for k in (0, 1):          # K10 + K9, K9 only -- each against the stock torch blocks
+            torch.testing.assert_close(outs[k][0], outs[2][0], rtol=1e-4, atol=1e-5)
+            for a, b in zip(outs[k][1], outs[2][1]):
+                torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-5 * float(b.abs().max()) + 1e-7)
+
+
+# ---------------------------------------------------------------------------------- K10: the encoder's first block, fused
+@pytest.mark.parametrize("B,Ci,Co,S", [(3, 1, 16, 128), (2, 3, 16, 84), (2, 1, 64, 12), (4, 2, 32, 10), (2, 1, 16, 2), (3, 3, 16, 7)])
+def test_first_block_matches_conv_relu_pool_forward_and_backward(H, B, Ci, Co, S):
+    """K10 vs conv2d(cat[obs, tiled state]) + ReLU + MaxPool2d(2) in plain PyTorch fp32 (src/nets/base_cnns.py:28-31 on the
+    input of src/models/robot_actor_critic.py:58-59): values, weight and bias gradients; borders, odd sizes, wide blocks."""
+    import torch.nn.functional as F
+    g = torch.Generator(device="cuda").manual_seed(100 * B + S)
+    obs = torch.rand(B, Ci, S, S, device="cuda", generator=g)
+    state = (torch.rand(B, device="cuda", generator=g) < 0.5).float()
+    w = (0.3 * torch.randn(Co, Ci + 1, 3, 3, device="cuda", generator=g))
+    b = 0.1 * torch.randn(Co, device="cuda", generator=g)
+    w1, b1 = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    x = torch.cat([obs, state.view(-1, 1, 1, 1).expand(B, 1, S, S)], 1)
+    with torch.backends.cudnn.flags(enabled=False):        # torch's own direct convolution: an fp32 reference without Winograd
+        ref = F.max_pool2d(F.relu(F.conv2d(x, w1, b1, padding=1)), 2)
+    gy = torch.randn(ref.shape, device="cuda", generator=g)
+    (ref * gy).sum().backward()
+    w2, b2 = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = H.first_block(obs, state, w2, b2)
+    (y * gy).sum().backward()
+    assert y.shape == ref.shape
+    torch.testing.assert_close(y, ref, rtol=1e-5, atol=2e-6)
+    sw, sb = float(w1.grad.abs().max()), float(b1.grad.abs().max())
+    assert float((w2.grad - w1.grad).abs().max()) <= 2e-5 * sw + 1e-6, (float((w2.grad - w1.grad).abs().max()), sw)
+    assert float((b2.grad - b1.grad).abs().max()) <= 2e-5 * sb + 1e-6
