@@ -50,6 +50,12 @@ constexpr int kCh = 4;       // operand prefetch depth of the MFMA chains (regis
 #define AURPPO_KCH_BIG 4     // prefetch depth of the 32- and 64-deep chains (A/B knob)
 #endif
 constexpr int kChB = AURPPO_KCH_BIG;
+#ifndef AURPPO_K7_CRITIC_VALU
+// Critic head (1 output) on the VALU + actor/critic roles swapped between the sets, so that every SIMD hosts one wave of each.
+// Built and measured in round 2: parity green, 5.6 % fewer matrix instructions per SIMD, and 1-2 % SLOWER (146.8 -> 148.5 us,
+// three alternating runs; 150 us with single-accumulator dot products): what a tile waits for is not the matrix pipe.  Off.
+#define AURPPO_K7_CRITIC_VALU 0
+#endif
 #ifndef AURPPO_BAR_SLEEP
 #define AURPPO_BAR_SLEEP 1   // s_sleep argument of the software barriers' poll loops (A/B knob; 0 = poll back to back)
 #endif
@@ -104,7 +110,11 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps set / net / cb and everything derived from them scalar
     const int set = wave >> 2, w = wave & 3, st = tid & (kSetThreads - 1);
-    const int net = w >> 1, cb = w & 1;
+    // Roles.  Wave w of either set sits on SIMD w.  The critic's one-output head is cheaper on the VALU than as padded matrix
+    // tiles (F3, dH2 and dW3: 20 of a wave's 180 MFMA-equivalents), which leaves the critic waves with less matrix work than
+    // the actor's -- so the sets take opposite roles per SIMD: every SIMD hosts one actor wave and one critic wave.
+    const int net = AURPPO_K7_CRITIC_VALU ? ((w >> 1) ^ set) : (w >> 1), cb = w & 1;
+    const int wi = net * 2 + cb;                 // role index: W1 operand slice, hand-over slot
     const int D = a.D, A = a.A;
     const int AW = a.continuous ? a.A : 1;
     const int out_dim[2] = {A, 1};
@@ -275,9 +285,10 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
     f32x16 gW2[2] = {zero16(), zero16()};
     f32x4 gW3[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // dW3 as two 16x16 blocks: rows = head outputs, cols cb*32 + 16*q + (lane & 15)
     float gb1 = 0.0f, gb2 = 0.0f;
+    float gw3c = 0.0f;      // critic waves (VALU head): dW3[0][cb*32 + lane], lanes 0..31
     float g_b3a[2] = {0.0f, 0.0f}, g_ls[2] = {0.0f, 0.0f}, g_b3c = 0.0f;   // loss-lane (row, j) partial column sums
 
-    const float* __restrict__ w1p = a.w1op + (size_t)w * 32 * kWave;
+    const float* __restrict__ w1p = a.w1op + (size_t)wi * 32 * kWave;
     const bool vec4 = (D % 4 == 0) && ((reinterpret_cast<size_t>(a.obs) & 15) == 0);
     // packed records (actions == nullptr): a sample's action row sits behind its 16-B record in one 64-B line
     const float* const act_base = a.actions ? a.actions : reinterpret_cast<const float*>(a.rec) + 4;
@@ -443,7 +454,22 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
         STAMP2(2);
         pair_bar();
         STAMP2(10);
-        {   // ---- F3: head (R x AP), each wave of a net takes 16 of the 32 rows
+        if (AURPPO_K7_CRITIC_VALU && net == 1) {
+            // ---- F3, critic: v[row] = H2[row] . w3 + b3 for this wave's 16 rows; lane = (k quarter, row): 16 rows x 4 quarters
+            // of 16 inputs each (row stride LD is odd, so a half-wave's 16 rows x 2 quarters hit 32 different banks)
+            const int r = ln & 15, kq = ln >> 4;
+            const float* Hrow = sH2 + (R + cb * 16 + r) * LD + kq * 16;
+            const float* Wc = sW3 + AP * LD + kq * 16;             // row 0 of the critic's head
+            float hv[16], wv[16], s4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { hv[k] = Hrow[k]; wv[k] = Wc[k]; }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) s4[k & 3] = fmaf(hv[k], wv[k], s4[k & 3]);
+            float sacc = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+            sacc += __shfl_xor(sacc, 16, kWave);
+            sacc += __shfl_xor(sacc, 32, kWave);
+            if (kq == 0) sOut[(R + cb * 16 + r) * LDO] = sacc + sB3[AP];
+        } else {   // ---- F3: head (R x AP), each wave of a net takes 16 of the 32 rows
             const float* W = sW3 + net * AP * LD;
             const float* Hin = sH2 + (net * R + cb * 16) * LD;
             const f32x4 acc = mma16<H, true>([&](int i, int k) { return Hin[i * LD + k]; },
@@ -533,6 +559,22 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
             const float* W3 = sW3 + net * AP * LD;
             float* H2 = sH2 + net * R * LD;
             f32x16 acc = zero16();
+            if (AURPPO_K7_CRITIC_VALU && net == 1) {
+                // critic: one output.  dH2[row][col] = g_v[row] * w3[col] (an outer product), dW3[col] += sum_rows g_v[row] * H2[row][col]
+                const int cl = cb * 32 + (ln & 31);
+                const float w3c = W3[cl];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e] = dO[acc_row(e, ln) * LDO] * w3c;
+                const int r0 = (ln >> 5) * 16;
+                float gv[16], hv[16], s4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { gv[r] = dO[(r0 + r) * LDO]; hv[r] = H2[(r0 + r) * LD + cl]; }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s4[r & 3] = fmaf(gv[r], hv[r], s4[r & 3]);
+                float sacc = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+                sacc += __shfl_xor(sacc, 32, kWave);
+                gw3c += sacc;
+            } else {
             // dH2 = dO . W3 over the head's outputs: columns past the head width are zero, so K = 8 covers a head of up to
             // 8 outputs (and the critic's single one) with half the matrix instructions of the padded 16
             if (A <= 8 || net == 1)
@@ -545,6 +587,7 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
             for (int q = 0; q < 2; ++q)
                 gW3[q] += mma16<R, true>([&](int i, int k) { return dO[k * LDO + i]; },
                                          [&](int k, int j) { return H2[k * LD + cb * 32 + 16 * q + j]; }, ln);
+            }
             const int col = cb * 32 + (ln & 31);
             float colsum = 0.0f;
 #pragma unroll
@@ -613,7 +656,7 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
     int le = lane, se = st;   // fresh opaque copies: nothing lane-derived has to stay live across the tile loop
     asm volatile("" : "+v"(le), "+v"(se));
     // ---- hand-over: set 1 parks its accumulators in the (dead) tile memory, set 0 adds them and writes the slab
-    float* park = lds + (size_t)w * kAccRegs * kWave + le;   // [wave][reg][le]
+    float* park = lds + (size_t)wi * kAccRegs * kWave + le;   // [role][reg][le]: set 0's wave of the same role reads it
     // head-side column sums: fold the 8 rows a wave's loss lanes cover
     float hs[5] = {g_b3a[0], g_b3a[1], g_ls[0], g_ls[1], (se & 7) == 0 ? g_b3c : 0.0f};
 #pragma unroll
@@ -639,9 +682,10 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
             park[(64 + e) * kWave] = gW3[0][e];
             park[(68 + e) * kWave] = gW3[1][e];
         }
+        if (AURPPO_K7_CRITIC_VALU && net == 1) park[64 * kWave] = gw3c;      // (gW3 is unused by a VALU-head critic wave)
         if (le < 32) {
-            s_gb[w][0][le] = gb1;
-            s_gb[w][1][le] = gb2;
+            s_gb[wi][0][le] = gb1;
+            s_gb[wi][1][le] = gb2;
         }
     }
     __syncthreads();
@@ -657,17 +701,21 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
                 slab[a.L.w2[net] + o * H + col] = gW2[ob][e] + park[(32 + ob * 16 + e) * kWave];
             }
         }
+        if (AURPPO_K7_CRITIC_VALU && net == 1) {
+            if (le < 32) slab[a.L.w3[1] + cb * 32 + le] = gw3c + park[64 * kWave];
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int o = 4 * (le >> 4) + e, c = cb * 32 + (le & 15);   // 16x16 accumulator layout
-            if (o < out_dim[net]) {
-                slab[a.L.w3[net] + o * H + c] = gW3[0][e] + park[(64 + e) * kWave];
-                slab[a.L.w3[net] + o * H + c + 16] = gW3[1][e] + park[(68 + e) * kWave];
+            for (int e = 0; e < 4; ++e) {
+                const int o = 4 * (le >> 4) + e, c = cb * 32 + (le & 15);   // 16x16 accumulator layout
+                if (o < out_dim[net]) {
+                    slab[a.L.w3[net] + o * H + c] = gW3[0][e] + park[(64 + e) * kWave];
+                    slab[a.L.w3[net] + o * H + c + 16] = gW3[1][e] + park[(68 + e) * kWave];
+                }
             }
         }
         if (le < 32) {
-            slab[a.L.b1[net] + col] = gb1 + s_gb[w][0][le];
-            slab[a.L.b2[net] + col] = gb2 + s_gb[w][1][le];
+            slab[a.L.b1[net] + col] = gb1 + s_gb[wi][0][le];
+            slab[a.L.b2[net] + col] = gb2 + s_gb[wi][1][le];
         }
         if (w == 0) {
             // head biases / log-std: le = action dim k (< 16): column sums over all 8 waves, fixed order
