@@ -383,27 +383,46 @@ __global__ __launch_bounds__(kFbThreads) void k_first_block_bwd(const float* __r
 extern "C" int aurppo_first_block_fwd_f32(const float* obs, const float* w, const float* bias, const float* state, float* y,
                                           uint8_t* mask, int B, int Ci, int Co, int H, int W, void* stream) {
     AURPPO_REQUIRE(obs && w && state && y && mask, AURPPO_EINVAL, "aurppo_first_block_fwd_f32: null pointer");
-    AURPPO_REQUIRE(B > 0 && B <= 65535 && Ci >= 1 && Ci <= 3 && Co > 0 && Co % kFbCo == 0 && Co / kFbCo <= 65535 && H >= 2 && W >= 2,
+    AURPPO_REQUIRE(B > 0 && Ci >= 1 && Ci <= 3 && Co > 0 && Co % kFbCo == 0 && Co / kFbCo <= 65535 && H >= 2 && W >= 2,
                    AURPPO_ESHAPE, "aurppo_first_block_fwd_f32: B=%d Ci=%d Co=%d H=%d W=%d (Ci in 1..3, Co a multiple of 16)", B, Ci, Co, H, W);
-    const dim3 grid(((H / 2) * (W / 2) + kFbThreads - 1) / kFbThreads, Co / kFbCo, B);
     hipStream_t s = (hipStream_t)stream;
-    if (Ci == 1) hipLaunchKernelGGL(k_first_block_fwd<1>, grid, dim3(kFbThreads), 0, s, obs, w, bias, state, y, mask, Co, H, W);
-    else if (Ci == 2) hipLaunchKernelGGL(k_first_block_fwd<2>, grid, dim3(kFbThreads), 0, s, obs, w, bias, state, y, mask, Co, H, W);
-    else hipLaunchKernelGGL(k_first_block_fwd<3>, grid, dim3(kFbThreads), 0, s, obs, w, bias, state, y, mask, Co, H, W);
-    AURPPO_LAUNCH_CHECK("k_first_block_fwd");
+    const size_t in_s = (size_t)Ci * H * W, out_s = (size_t)Co * (H / 2) * (W / 2);
+    for (int b0 = 0; b0 < B; b0 += 65535) {          // the sample index rides in gridDim.z (<= 65535): larger batches in slices
+        const int nb = B - b0 < 65535 ? B - b0 : 65535;
+        const dim3 grid(((H / 2) * (W / 2) + kFbThreads - 1) / kFbThreads, Co / kFbCo, nb);
+        const float* o = obs + b0 * in_s;
+        const float* st = state + b0;
+        float* yy = y + b0 * out_s;
+        uint8_t* mm = mask + b0 * out_s;
+        if (Ci == 1) hipLaunchKernelGGL(k_first_block_fwd<1>, grid, dim3(kFbThreads), 0, s, o, w, bias, st, yy, mm, Co, H, W);
+        else if (Ci == 2) hipLaunchKernelGGL(k_first_block_fwd<2>, grid, dim3(kFbThreads), 0, s, o, w, bias, st, yy, mm, Co, H, W);
+        else hipLaunchKernelGGL(k_first_block_fwd<3>, grid, dim3(kFbThreads), 0, s, o, w, bias, st, yy, mm, Co, H, W);
+        AURPPO_LAUNCH_CHECK("k_first_block_fwd");
+    }
     return AURPPO_OK;
 }
 
 extern "C" int aurppo_first_block_bwd_f32(const float* dy, const uint8_t* mask, const float* obs, const float* state,
                                           float* dw_part, float* db_part, int B, int Ci, int Co, int H, int W, void* stream) {
     AURPPO_REQUIRE(dy && mask && obs && state && dw_part && db_part, AURPPO_EINVAL, "aurppo_first_block_bwd_f32: null pointer");
-    AURPPO_REQUIRE(B > 0 && B <= 65535 && Ci >= 1 && Ci <= 3 && Co > 0 && Co % kFbCo == 0 && Co / kFbCo <= 65535 && H >= 2 && W >= 2,
+    AURPPO_REQUIRE(B > 0 && Ci >= 1 && Ci <= 3 && Co > 0 && Co % kFbCo == 0 && Co / kFbCo <= 65535 && H >= 2 && W >= 2,
                    AURPPO_ESHAPE, "aurppo_first_block_bwd_f32: B=%d Ci=%d Co=%d H=%d W=%d", B, Ci, Co, H, W);
-    const dim3 grid(1, Co / kFbCo, B);
     hipStream_t s = (hipStream_t)stream;
-    if (Ci == 1) hipLaunchKernelGGL(k_first_block_bwd<1>, grid, dim3(kFbThreads), 0, s, dy, mask, obs, state, dw_part, db_part, Co, H, W);
-    else if (Ci == 2) hipLaunchKernelGGL(k_first_block_bwd<2>, grid, dim3(kFbThreads), 0, s, dy, mask, obs, state, dw_part, db_part, Co, H, W);
-    else hipLaunchKernelGGL(k_first_block_bwd<3>, grid, dim3(kFbThreads), 0, s, dy, mask, obs, state, dw_part, db_part, Co, H, W);
-    AURPPO_LAUNCH_CHECK("k_first_block_bwd");
+    const size_t in_s = (size_t)Ci * H * W, out_s = (size_t)Co * (H / 2) * (W / 2);
+    const size_t g_s = (size_t)(Co / kFbCo) * kFbCo;             // partial-sum rows per sample
+    for (int b0 = 0; b0 < B; b0 += 65535) {
+        const int nb = B - b0 < 65535 ? B - b0 : 65535;
+        const dim3 grid(1, Co / kFbCo, nb);
+        const float* g = dy + b0 * out_s;
+        const uint8_t* mm = mask + b0 * out_s;
+        const float* o = obs + b0 * in_s;
+        const float* st = state + b0;
+        float* dwp = dw_part + b0 * g_s * (size_t)((Ci + 1) * 9);
+        float* dbp = db_part + b0 * g_s;
+        if (Ci == 1) hipLaunchKernelGGL(k_first_block_bwd<1>, grid, dim3(kFbThreads), 0, s, g, mm, o, st, dwp, dbp, Co, H, W);
+        else if (Ci == 2) hipLaunchKernelGGL(k_first_block_bwd<2>, grid, dim3(kFbThreads), 0, s, g, mm, o, st, dwp, dbp, Co, H, W);
+        else hipLaunchKernelGGL(k_first_block_bwd<3>, grid, dim3(kFbThreads), 0, s, g, mm, o, st, dwp, dbp, Co, H, W);
+        AURPPO_LAUNCH_CHECK("k_first_block_bwd");
+    }
     return AURPPO_OK;
 }

@@ -112,8 +112,20 @@ class EquivariantEncoder(nn.Module):
             raise ValueError(f"EquivariantEncoder: observations must be 128x128 or 84x84, got {obs_size}")
         self.conv = nn.Sequential(*[_Block(C4Conv(i, o, t, "regular", 3, pad), pool) for (i, o, t, pad, pool) in spec])
 
-    def forward(self, x):
-        return self.conv(x)
+    def forward(self, x, state=None):
+        """``x``: the observation with the tiled gripper state as its last channel (upstream's input), or -- with ``state``
+        given -- the image channels alone: on the GPU the first block then runs as K10 (the state is a constant plane, a
+        trivial input field, so nothing about the symmetry changes)."""
+        if state is None:
+            return self.conv(x)
+        first = self.conv[0]
+        if (x.is_cuda and first.pool == 2 and getattr(first, "fused_pool", True) and x.shape[1] <= 3
+                and (first.conv.out_fields * 4) % 16 == 0):
+            from . import hip_ops as H
+            y = H.first_block(x, state, first.conv.expanded_weight(), first.conv.expanded_bias())
+            return self.conv[1:](y)
+        cat = torch.cat([x, state.reshape(-1, 1, 1, 1).to(x.dtype).expand(x.shape[0], 1, x.shape[2], x.shape[3])], dim=1)
+        return self.conv(cat)
 
 
 class EquivariantActor(nn.Module):
@@ -130,9 +142,9 @@ class EquivariantActor(nn.Module):
         self.w_inv = nn.Parameter(torch.randn(2 * action_dim - 2, n_hidden) * s)
         self.b_inv = nn.Parameter(torch.zeros(2 * action_dim - 2))            # (an irrep(1) output admits no bias)
 
-    def forward(self, obs):
+    def forward(self, obs, state=None):
         B = obs.shape[0]
-        f = self.enc(obs).reshape(B, self.n_hidden, 4)                        # (B, field, g)
+        f = self.enc(obs, state).reshape(B, self.n_hidden, 4)                 # (B, field, g)
         # R(g) u for the four rotations: (x, y) -> (-y, x) per quarter turn
         u = self.w_vec
         rot = torch.stack([u, torch.stack([-u[:, 1], u[:, 0]], 1), -u, torch.stack([u[:, 1], -u[:, 0]], 1)], dim=1)   # (field, g, 2)
@@ -164,6 +176,6 @@ class EquivariantCritic(nn.Module):
         self.critic = nn.Sequential(_Block(C4Conv(n_hidden, n_hidden, "regular", "regular", 1, 0)), GroupPool(),
                                     nn.Conv2d(n_hidden, 1, kernel_size=1))
 
-    def forward(self, obs):
-        out = self.critic(self.img_conv(obs))
+    def forward(self, obs, state=None):
+        out = self.critic(self.img_conv(obs, state))
         return out.as_subclass(_GeoValue)

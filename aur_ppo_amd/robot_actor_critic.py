@@ -59,7 +59,7 @@ class robot_actor_critic(nn.Module):
 
     def value(self, state, obs):
         if self.equivariant:          # the tiled state is a constant plane: a trivial (rotation-invariant) input field
-            return self.critic(self._cat(state.to(self.device), obs.to(self.device)))
+            return self.critic(obs.to(self.device), state.to(self.device))
         # upstream tiles the gripper state to a plane and concatenates it (:58-59); folded into conv 1 here
         return self.critic(obs.to(self.device), state.to(self.device), self.memory_format)
 
@@ -88,9 +88,8 @@ class robot_actor_critic(nn.Module):
 
     def evaluate(self, state, obs, action=None):
         state, obs = state.to(self.device), obs.to(self.device)
-        if self.equivariant:          # src/models/robot_actor_critic.py:109-110
-            cat_obs = self._cat(state, obs)
-            mean, logstd = self.actor(cat_obs)
+        if self.equivariant:          # src/models/robot_actor_critic.py:109-110 (the tile + concat happens inside the nets)
+            mean, logstd = self.actor(obs, state)
         else:
             mean = self.actor(obs, state, self.memory_format)
             logstd = self.actor_logstd.expand_as(mean)
@@ -102,12 +101,12 @@ class robot_actor_critic(nn.Module):
         entropy = (0.5 + _HALF_LOG_2PI + logstd).sum(1)
         unscaled_actions, actions = self.decodeActions(*[action[:, i] for i in range(self.n_a)])
         if self.equivariant:
-            return actions, unscaled_actions, log_prob, entropy, self.critic(cat_obs)
+            return actions, unscaled_actions, log_prob, entropy, self.critic(obs, state)
         return actions, unscaled_actions, log_prob, entropy, self.critic(obs, state, self.memory_format)
 
     def test_action(self, state, obs):
         if self.equivariant:
-            mean = torch.tanh(self.actor(self._cat(state.to(self.device), obs.to(self.device)))[0])
+            mean = torch.tanh(self.actor(obs.to(self.device), state.to(self.device))[0])
             return self.decodeActions(*[mean[:, i] for i in range(self.n_a)])
         mean = torch.tanh(self.actor(obs.to(self.device), state.to(self.device), self.memory_format))
         return self.decodeActions(*[mean[:, i] for i in range(self.n_a)])

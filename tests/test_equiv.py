@@ -98,9 +98,10 @@ def test_equiv_on_gpu():
     """Same property through the GPU path (MIOpen convolutions + K9 blocks), and one robot_ppo update with the
     equivariant policy on the HIP kernels."""
     torch.manual_seed(3)
-    actor = EquivariantActor(obs_shape=(2, 128, 128), action_dim=5, n_hidden=16).cuda()
-    critic = EquivariantCritic(obs_shape=(2, 128, 128), n_hidden=16).cuda()
+    actor = EquivariantActor(obs_shape=(2, 128, 128), action_dim=5, n_hidden=32).cuda()      # first block: 4 fields x 4 = 16 channels (K10)
+    critic = EquivariantCritic(obs_shape=(2, 128, 128), n_hidden=32).cuda()
     obs = torch.rand(4, 2, 128, 128, device="cuda")
+    obs[:, 1] = (torch.rand(4, device="cuda") < 0.5).float().view(4, 1, 1)       # channel 1: the tiled gripper state
     with torch.no_grad():
         mean, log_std = actor(obs)
         v = critic(obs)
@@ -109,7 +110,10 @@ def test_equiv_on_gpu():
         torch.testing.assert_close(m2[:, [0, 3, 4]], mean[:, [0, 3, 4]], rtol=1e-3, atol=1e-5)
         torch.testing.assert_close(ls2, log_std, rtol=1e-3, atol=1e-5)
         torch.testing.assert_close(critic(torch.rot90(obs, 1, (2, 3))).tensor, v.tensor, rtol=1e-3, atol=1e-5)
-        # K9 blocks == stock torch blocks
+        # K10 first block (image and state given separately) == K9 blocks on the concatenated input == stock torch blocks
+        m4, ls4 = actor(obs[:, :1].contiguous(), obs[:, 1, 0, 0].contiguous())
+        torch.testing.assert_close(m4, mean, rtol=1e-4, atol=1e-6)
+        torch.testing.assert_close(critic(obs[:, :1].contiguous(), obs[:, 1, 0, 0].contiguous()).tensor, v.tensor, rtol=1e-4, atol=1e-6)
         for b in actor.enc.conv:
             b.fused_pool = False
         m3, _ = actor(obs)
@@ -118,7 +122,7 @@ def test_equiv_on_gpu():
     from aur_ppo_amd.robot_run import build_parser, params_from_args
     p = params_from_args(build_parser().parse_args([]))
     p.update(gym_id="Synthetic-arm", num_envs=4, num_steps=4, total_timesteps=32, num_update_epochs=2, num_minibatches=2,
-             do_pretraining=False, log=False, equivariant=True, equiv_hidden=16)
+             do_pretraining=False, log=False, equivariant=True, equiv_hidden=32)
     a = robot_ppo(p)
     a.train()
     assert np.isfinite(a._last_scalars).all() and a._last_scalars.shape == (4, 9)

@@ -457,3 +457,23 @@ def test_first_block_matches_conv_relu_pool_forward_and_backward(H, B, Ci, Co, S
     sw, sb = float(w1.grad.abs().max()), float(b1.grad.abs().max())
     assert float((w2.grad - w1.grad).abs().max()) <= 2e-5 * sw + 1e-6, (float((w2.grad - w1.grad).abs().max()), sw)
     assert float((b2.grad - b1.grad).abs().max()) <= 2e-5 * sb + 1e-6
+
+
+def test_first_block_batches_past_the_grid_limit(H):
+    """gridDim.z carries the sample index (<= 65535): a larger batch goes in slices and must equal two half-batch calls."""
+    B, S = 70000, 4
+    g = torch.Generator(device="cuda").manual_seed(1)
+    obs = torch.rand(B, 1, S, S, device="cuda", generator=g)
+    state = (torch.rand(B, device="cuda", generator=g) < 0.5).float()
+    w = (0.3 * torch.randn(16, 2, 3, 3, device="cuda", generator=g)).requires_grad_(True)
+    b = (0.1 * torch.randn(16, device="cuda", generator=g)).requires_grad_(True)
+    y = H.first_block(obs, state, w, b)
+    gy = torch.randn(y.shape, device="cuda", generator=g)
+    (y * gy).sum().backward()
+    w2, b2 = w.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+    h = B // 2
+    ya, yb = H.first_block(obs[:h], state[:h], w2, b2), H.first_block(obs[h:], state[h:], w2, b2)
+    ((ya * gy[:h]).sum() + (yb * gy[h:]).sum()).backward()
+    assert torch.equal(y, torch.cat([ya, yb]))
+    torch.testing.assert_close(w.grad, w2.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(b.grad, b2.grad, rtol=1e-4, atol=1e-4)
