@@ -306,6 +306,9 @@ class robot_ppo(FlatAdamMixin):
             srcs = [b_obs, b_actions, b_states, b_logprobs, b_advantages, b_returns, b_values]
         if self.rng is None:
             self.seed_all(1)
+        # all epochs' permutations are drawn up front; upstream draws one per epoch it actually runs (src/robot_ppo.py:338), so an
+        # early stop on target_kl must leave the generator where numpy's would be: snapshot here, replay on the break below
+        snapshot = self.rng.get_state() if self.target_kl is not None else None
         perms = self.rng.shuffle_epochs(batch_size, update_epochs)
         self._adopt_lr()
         vmode = ops.VLOSS_CLIPPED if self.clip_vloss else ops.VLOSS_RETURNS     # src/robot_ppo.py:379-390
@@ -339,6 +342,9 @@ class robot_ppo(FlatAdamMixin):
                     torch.distributed.all_reduce(kl)
                     kl /= self.world
                 if float(kl) > self.target_kl:
+                    if ep + 1 < update_epochs:
+                        self.rng.set_state(*snapshot)
+                        self.rng.shuffle_epochs(batch_size, ep + 1)
                     break
         flag = torch.zeros(1, device=self.device)
         if hasattr(self.rng, "status_into"):

@@ -107,3 +107,18 @@ def test_channels_last_option_gives_the_same_numbers():
     v0 = a.policy.value(s, o).detach().clone()
     a.policy.memory_format = torch.channels_last
     np.testing.assert_allclose(a.policy.value(s, o).detach().numpy(), v0.numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_target_kl_early_stop_leaves_the_generator_where_numpy_would_be():
+    """src/robot_ppo.py:338,406-408: upstream shuffles once per epoch it runs; a stop after epoch 1 must have consumed ONE
+    shuffle of the global stream, not ``update_epochs`` of them."""
+    a = robot_ppo(_params(target_kl=-1.0, num_update_epochs=3), ops=oracle_ops)
+    a.seed_all(1)
+    ret, adv = a.advantages(*a.envs.reset(), torch.zeros(2), a.buffer, a.num_steps)
+    a.update(a.buffer.flatten(ret, adv), 3, a.batch_size, a.minibatch_size, [])
+    assert a._last_scalars.shape[0] == 2                      # one epoch x 2 minibatches
+    rs = np.random.RandomState(1)
+    rs.shuffle(np.arange(a.batch_size))
+    key, pos = a.rng.get_state()
+    np.testing.assert_array_equal(key, rs.get_state()[1])
+    assert pos == rs.get_state()[2]
