@@ -519,8 +519,9 @@ __global__ void k_fy_link(const int32_t* __restrict__ j, int32_t* __restrict__ h
 __global__ void k_fy_resolve(const int32_t* __restrict__ j, const int32_t* __restrict__ head,
                              const int32_t* __restrict__ next, const int32_t* __restrict__ in,
                              int32_t* __restrict__ out, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+  // grid-stride: a bounded grid (AURPPO_K2_RESOLVE_WGS) keeps the kernel on the few CUs K7 leaves free instead of queueing
+  // thousands of short workgroups behind it
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int kNone = 0x7fffffff;
     int src;
     int cur = i;
@@ -553,6 +554,7 @@ __global__ void k_fy_resolve(const int32_t* __restrict__ j, const int32_t* __res
         src = cur;
     }
     out[i] = in ? in[src] : src;
+  }
 }
 
 // sticky "a shuffle ran out of draws" flag as a float, for the trainer's once-per-update scalar read
@@ -603,22 +605,31 @@ static hipError_t own_cu_setup() {
     return e;
 }
 
+// Diagnostic knob AURPPO_K2_ONE_STREAM=1: the twist and the resolves run on the caller's stream too (everything serial) -- used
+// to tell how much of the main stream's slowdown comes from HOW MANY streams are busy rather than from what runs on them.
+static hipStream_t fill_stream_of(aurppo_rng* rng, hipStream_t s) {
+    static const bool one = [] { const char* e = getenv("AURPPO_K2_ONE_STREAM"); return e && *e == '1'; }();
+    return one ? s : rng->fill_stream;
+}
+
 static int enqueue_fill(aurppo_rng* rng, double need, hipStream_t after, int slot, int cur_slot) {
+    const hipStream_t fs = fill_stream_of(rng, after);
     // inventory target 2*need: one shuffle may be consuming while the next one's draws are produced
     AURPPO_HIP_TRY(hipEventRecord(rng->ev_sync, after));
-    AURPPO_HIP_TRY(hipStreamWaitEvent(rng->fill_stream, rng->ev_sync, 0));
+    AURPPO_HIP_TRY(hipStreamWaitEvent(fs, rng->ev_sync, 0));
     const int nblk_max = (int)(2.0 * need / kMtN) + 2;
     AURPPO_HIP_TRY(own_cu_setup());
-    hipLaunchKernelGGL(k_mt_fill, dim3(1), dim3(kFillAll), kOwnCuLds, rng->fill_stream, rng->d_last, rng->d_ring,
+    hipLaunchKernelGGL(k_mt_fill, dim3(1), dim3(kFillAll), kOwnCuLds, fs, rng->d_last, rng->d_ring,
                        (long long)rng->ring_cap, rng->d_pos, (long long)(2.0 * need), nblk_max, cur_slot);
     AURPPO_LAUNCH_CHECK("k_mt_fill");
-    AURPPO_HIP_TRY(hipEventRecord(rng->ev_fill[slot], rng->fill_stream));
+    AURPPO_HIP_TRY(hipEventRecord(rng->ev_fill[slot], fs));
     return AURPPO_OK;
 }
 
 constexpr int kClrChunk = 4096;         // head buffers are sized and cleared in whole chunks
 
 int permute_once(aurppo_rng* rng, const int32_t* in, int32_t* out, int n, hipStream_t s) {
+    const hipStream_t fs = fill_stream_of(rng, s);
     const double need = need_words(n);
     if (2.0 * need + 4.0 * kMtN > (double)rng->ring_cap) {
         aurppo_set_error("shuffle: word ring too small for n=%d", n);
@@ -674,19 +685,28 @@ int permute_once(aurppo_rng* rng, const int32_t* in, int32_t* out, int n, hipStr
     // covers), then THIS shuffle's resolve.  The caller's stream is then free for the next accept while the resolve
     // runs: per shuffle the two streams carry {accept, link} and {fill, resolve} instead of {accept, memset, link,
     // resolve} and {fill}.
-    if (rng->seq > 0) AURPPO_HIP_TRY(hipStreamWaitEvent(rng->fill_stream, rng->ev_acc[slot ^ 1], 0));
+    if (rng->seq > 0) AURPPO_HIP_TRY(hipStreamWaitEvent(fs, rng->ev_acc[slot ^ 1], 0));
     {
         const int nblk_max = (int)(2.0 * need / kMtN) + 2;
-        hipLaunchKernelGGL(k_mt_fill, dim3(1), dim3(kFillAll), kOwnCuLds, rng->fill_stream, rng->d_last, rng->d_ring,
+        hipLaunchKernelGGL(k_mt_fill, dim3(1), dim3(kFillAll), kOwnCuLds, fs, rng->d_last, rng->d_ring,
                            (long long)rng->ring_cap, rng->d_pos, (long long)(2.0 * need), nblk_max,
                            rng->seq > 0 ? 4 + (slot ^ 1) : 1);   // cursor after the PREVIOUS shuffle (done: waited above)
         AURPPO_LAUNCH_CHECK("k_mt_fill");
-        AURPPO_HIP_TRY(hipEventRecord(rng->ev_fill[slot ^ 1], rng->fill_stream));
+        AURPPO_HIP_TRY(hipEventRecord(rng->ev_fill[slot ^ 1], fs));
     }
-    hipStream_t rs = rng->use_post ? rng->post_stream : rng->fill_stream;
+    hipStream_t rs = rng->use_post ? rng->post_stream : fs;
     if (!rng->use_post) AURPPO_HIP_TRY(hipStreamWaitEvent(rs, rng->ev_link[slot], 0));
-    hipLaunchKernelGGL(k_fy_resolve, dim3(grid), dim3(256), 0, rs, rng->d_j[slot], rng->d_head[h],
-                       rng->d_next[slot], in, out, n);
+    static int resolve_wgs = -1;
+    if (resolve_wgs < 0) {
+        const char* e = getenv("AURPPO_K2_RESOLVE_WGS");
+        // default 256 workgroups striding over the positions (0 = one per 256 positions, 2048 of them at B = 524 288).
+        // Round 1 had no slack on the shuffle streams to pay for a slower resolve; with 0.5 ms of it (round 2) a bounded
+        // grid is affordable: 64 / 128 / 192 / 256 / 512 workgroups -> main stream +17 % (shuffle-bound) / -1.2 % (slack 0)
+        // / -0.9 % (slack 0.17 ms) / -0.6 % (0.28 ms) / -0.6 % (0.37 ms), alternating runs on one box.
+        resolve_wgs = e && *e ? atoi(e) : 256;
+    }
+    hipLaunchKernelGGL(k_fy_resolve, dim3(resolve_wgs > 0 && resolve_wgs < grid ? resolve_wgs : grid), dim3(256), 0, rs,
+                       rng->d_j[slot], rng->d_head[h], rng->d_next[slot], in, out, n);
     AURPPO_LAUNCH_CHECK("k_fy_resolve");
     AURPPO_HIP_TRY(hipEventRecord(rng->ev_res, rs));
     if (rng->use_post) AURPPO_HIP_TRY(hipEventRecord(rng->ev_post[slot], rs));
