@@ -314,67 +314,96 @@ __global__ __launch_bounds__(kFbThreads) void k_first_block_fwd(const float* __r
     }
 }
 
-// grid: (1, Co / 16, B): one workgroup per sample and channel group walks all pooled elements and leaves
-// dw_part[(b * Co/16 + cg)][16][(CI+1)*9] and db_part[...][16].
+// grid: (1, Co / 16, B): one workgroup of 16 waves per sample and channel group, ONE WAVE PER OUTPUT CHANNEL; a wave walks all
+// pooled elements of its channel and leaves dw_part[(b * Co/16 + cg)][channel][(CI+1)*9] and db_part[...][channel].
+// (First version: 256 threads walking the 16 channels one after the other -- PMC showed 8.1 GB fetched against 3.2 GB
+// algorithmic: the observation was re-read from beyond L2 once per channel.  Sixteen waves sweeping the same image together share
+// it through the CU's L1, and a channel's sums are a wave reduction -- DPP, no LDS, no barrier.)
+constexpr int kFbBwdThreads = kFbCo * kWave;
+
 template <int CI>
-__global__ __launch_bounds__(kFbThreads) void k_first_block_bwd(const float* __restrict__ dy, const uint8_t* __restrict__ mask,
-                                                                const float* __restrict__ obs,
-                                                                const float* __restrict__ state,
-                                                                float* __restrict__ dw_part, float* __restrict__ db_part,
-                                                                int Co, int H, int W) {
+__global__ __launch_bounds__(kFbBwdThreads) void k_first_block_bwd(const float* __restrict__ dy, const uint8_t* __restrict__ mask,
+                                                                   const float* __restrict__ obs,
+                                                                   const float* __restrict__ state,
+                                                                   float* __restrict__ dw_part, float* __restrict__ db_part,
+                                                                   int Co, int H, int W) {
     constexpr int NT = (CI + 1) * 9;
-    __shared__ float s_red[kFbThreads / kWave][NT + 1];
     const int Ho = H >> 1, Wo = W >> 1;
     const int cg = blockIdx.y, b = blockIdx.z;
     const float sv = state[b];
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-    for (int cc = 0; cc < kFbCo; ++cc) {
-        const int c = cg * kFbCo + cc;
-        const float* gp = dy + ((size_t)b * Co + c) * Ho * Wo;
-        const uint8_t* mp = mask + ((size_t)b * Co + c) * Ho * Wo;
-        float a[NT + 1];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int cc = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);      // this wave's channel within the group
+    const int c = cg * kFbCo + cc;
+    const float* gp = dy + ((size_t)b * Co + c) * Ho * Wo;
+    const uint8_t* mp = mask + ((size_t)b * Co + c) * Ho * Wo;
+    const float* ob = obs + (size_t)b * CI * H * W;
+    // a[0 .. CI*9): image taps; then nine running sums of the output gradient for the state plane's taps (all / first row /
+    // last row / first column / last column / four corners: a tap's gradient is all - excluded row - excluded column + corner)
+    constexpr int NA = CI * 9 + 9;
+    float a[NA];
 #pragma unroll
-        for (int t = 0; t <= NT; ++t) a[t] = 0.0f;
-        for (int q = threadIdx.x; q < Ho * Wo; q += kFbThreads) {
-            const int mk = mp[q];
-            if (mk >= 4) continue;
-            const float g = gp[q];
-            const int ho = q / Wo, wo = q - ho * Wo;
-            const int h = 2 * ho + (mk >> 1), ww = 2 * wo + (mk & 1);      // where the maximum sat
+    for (int t = 0; t < NA; ++t) a[t] = 0.0f;
+    const int dqh = kWave / Wo, dqw = kWave - dqh * Wo;             // a lane's position advances by 64 pooled elements
+    int ho = lane / Wo, wo = lane - ho * Wo;
+    // What paces this kernel is the vector-memory front end, not HBM (PMC: 3.1 GB fetched = algorithmic) and not arithmetic:
+    // nine scattered dword gathers per position and channel.  A window row is three consecutive floats, so it is ONE 12-byte
+    // load from a column base clamped into the image; the border cases pick their taps out of it with selects.
+    typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
+    for (int q = lane; q < Ho * Wo; q += kWave) {
+        const int mk = mp[q];
+        const float g = mk < 4 ? gp[q] : 0.0f;
+        const int h = 2 * ho + ((mk & 3) >> 1), ww = 2 * wo + (mk & 1);      // where the maximum sat
+        const bool t0 = h == 0, b0 = h == H - 1, l0 = ww == 0, r0 = ww == W - 1;
+        const int rr[3] = {(t0 ? 0 : h - 1) * W, h * W, (b0 ? h : h + 1) * W};      // clamped rows (a clamped row's weight is 0)
+        const int cb = l0 ? 0 : (r0 ? W - 3 : ww - 1);                              // first column of the 12-byte load (W >= 3)
+        const float gr[3] = {t0 ? 0.0f : g, g, b0 ? 0.0f : g};
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
-                const int hh = h + kh - 1;
-                const bool rv = hh >= 0 && hh < H;
+        for (int kh = 0; kh < 3; ++kh) {
+            const float gk[3] = {l0 ? 0.0f : gr[kh], gr[kh], r0 ? 0.0f : gr[kh]};
 #pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const int wx = ww + kw - 1;
-                    const bool in = rv && wx >= 0 && wx < W;
-#pragma unroll
-                    for (int ci = 0; ci < CI; ++ci) {
-                        const float x = in ? obs[(((size_t)b * CI + ci) * H + (in ? hh : 0)) * W + (in ? wx : 0)] : 0.0f;
-                        a[ci * 9 + kh * 3 + kw] = fmaf(g, x, a[ci * 9 + kh * 3 + kw]);
-                    }
-                    a[CI * 9 + kh * 3 + kw] += in ? g * sv : 0.0f;
-                }
+            for (int ci = 0; ci < CI; ++ci) {
+                const f32x3u v = *reinterpret_cast<const f32x3u*>(ob + (size_t)ci * H * W + rr[kh] + cb);
+                // columns ww-1, ww, ww+1: at the left border the load starts at column 0 (= ww), at the right one at W-3
+                const float x0 = r0 ? v.y : v.x;                    // (left border: weight 0, any value)
+                const float x1 = l0 ? v.x : (r0 ? v.z : v.y);
+                const float x2 = l0 ? v.y : v.z;                    // (right border: weight 0)
+                a[ci * 9 + kh * 3 + 0] = fmaf(gk[0], x0, a[ci * 9 + kh * 3 + 0]);
+                a[ci * 9 + kh * 3 + 1] = fmaf(gk[1], x1, a[ci * 9 + kh * 3 + 1]);
+                a[ci * 9 + kh * 3 + 2] = fmaf(gk[2], x2, a[ci * 9 + kh * 3 + 2]);
             }
-            a[NT] += g;
         }
-        // 256 threads -> one value each (fixed order: deterministic)
+        float* sg = a + CI * 9;
+        const float gt = t0 ? g : 0.0f, gb = b0 ? g : 0.0f;
+        sg[0] += g; sg[1] += gt; sg[2] += gb; sg[3] += l0 ? g : 0.0f; sg[4] += r0 ? g : 0.0f;
+        sg[5] += l0 ? gt : 0.0f; sg[6] += r0 ? gt : 0.0f; sg[7] += l0 ? gb : 0.0f; sg[8] += r0 ? gb : 0.0f;
+        wo += dqw; ho += dqh;
+        if (wo >= Wo) { wo -= Wo; ++ho; }
+    }
+    const size_t g_ = (size_t)b * gridDim.y + cg;
+    float red[NA];
 #pragma unroll
-        for (int t = 0; t <= NT; ++t) {
-            const float v = wave_sum_dpp(a[t]);
-            if (lane == 0) s_red[wave][t] = v;
-        }
-        __syncthreads();
-        if (threadIdx.x <= NT) {
-            float v = 0.0f;
+    for (int t = 0; t < NA; ++t) red[t] = wave_sum_dpp(a[t]);          // fixed order: deterministic; every lane holds the sums
+    if (lane == 0) {
+        float* dst = dw_part + (g_ * kFbCo + cc) * NT;
 #pragma unroll
-            for (int wv = 0; wv < kFbThreads / kWave; ++wv) v += s_red[wv][threadIdx.x];
-            const size_t g_ = (size_t)b * gridDim.y + cg;
-            if (threadIdx.x < NT) dw_part[(g_ * kFbCo + cc) * NT + threadIdx.x] = v;
-            else db_part[g_ * kFbCo + cc] = v;
-        }
-        __syncthreads();
+        for (int t = 0; t < CI * 9; ++t) dst[t] = red[t];
+        const float* G = red + CI * 9;         // all, top, bottom, left, right, tl, tr, bl, br
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                float v = G[0];
+                if (kh == 0) v -= G[1];
+                if (kh == 2) v -= G[2];
+                if (kw == 0) v -= G[3];
+                if (kw == 2) v -= G[4];
+                if (kh == 0 && kw == 0) v += G[5];
+                if (kh == 0 && kw == 2) v += G[6];
+                if (kh == 2 && kw == 0) v += G[7];
+                if (kh == 2 && kw == 2) v += G[8];
+                dst[CI * 9 + kh * 3 + kw] = sv * v;
+            }
+        db_part[g_ * kFbCo + cc] = G[0];
     }
 }
 
@@ -383,8 +412,8 @@ __global__ __launch_bounds__(kFbThreads) void k_first_block_bwd(const float* __r
 extern "C" int aurppo_first_block_fwd_f32(const float* obs, const float* w, const float* bias, const float* state, float* y,
                                           uint8_t* mask, int B, int Ci, int Co, int H, int W, void* stream) {
     AURPPO_REQUIRE(obs && w && state && y && mask, AURPPO_EINVAL, "aurppo_first_block_fwd_f32: null pointer");
-    AURPPO_REQUIRE(B > 0 && Ci >= 1 && Ci <= 3 && Co > 0 && Co % kFbCo == 0 && Co / kFbCo <= 65535 && H >= 2 && W >= 2,
-                   AURPPO_ESHAPE, "aurppo_first_block_fwd_f32: B=%d Ci=%d Co=%d H=%d W=%d (Ci in 1..3, Co a multiple of 16)", B, Ci, Co, H, W);
+    AURPPO_REQUIRE(B > 0 && Ci >= 1 && Ci <= 3 && Co > 0 && Co % kFbCo == 0 && Co / kFbCo <= 65535 && H >= 2 && W >= 3,
+                   AURPPO_ESHAPE, "aurppo_first_block_fwd_f32: B=%d Ci=%d Co=%d H=%d W=%d (Ci in 1..3, Co a multiple of 16, W >= 3)", B, Ci, Co, H, W);
     hipStream_t s = (hipStream_t)stream;
     const size_t in_s = (size_t)Ci * H * W, out_s = (size_t)Co * (H / 2) * (W / 2);
     for (int b0 = 0; b0 < B; b0 += 65535) {          // the sample index rides in gridDim.z (<= 65535): larger batches in slices
@@ -405,8 +434,8 @@ extern "C" int aurppo_first_block_fwd_f32(const float* obs, const float* w, cons
 extern "C" int aurppo_first_block_bwd_f32(const float* dy, const uint8_t* mask, const float* obs, const float* state,
                                           float* dw_part, float* db_part, int B, int Ci, int Co, int H, int W, void* stream) {
     AURPPO_REQUIRE(dy && mask && obs && state && dw_part && db_part, AURPPO_EINVAL, "aurppo_first_block_bwd_f32: null pointer");
-    AURPPO_REQUIRE(B > 0 && Ci >= 1 && Ci <= 3 && Co > 0 && Co % kFbCo == 0 && Co / kFbCo <= 65535 && H >= 2 && W >= 2,
-                   AURPPO_ESHAPE, "aurppo_first_block_bwd_f32: B=%d Ci=%d Co=%d H=%d W=%d", B, Ci, Co, H, W);
+    AURPPO_REQUIRE(B > 0 && Ci >= 1 && Ci <= 3 && Co > 0 && Co % kFbCo == 0 && Co / kFbCo <= 65535 && H >= 2 && W >= 3,
+                   AURPPO_ESHAPE, "aurppo_first_block_bwd_f32: B=%d Ci=%d Co=%d H=%d W=%d (W >= 3)", B, Ci, Co, H, W);
     hipStream_t s = (hipStream_t)stream;
     const size_t in_s = (size_t)Ci * H * W, out_s = (size_t)Co * (H / 2) * (W / 2);
     const size_t g_s = (size_t)(Co / kFbCo) * kFbCo;             // partial-sum rows per sample
@@ -419,9 +448,9 @@ extern "C" int aurppo_first_block_bwd_f32(const float* dy, const uint8_t* mask, 
         const float* st = state + b0;
         float* dwp = dw_part + b0 * g_s * (size_t)((Ci + 1) * 9);
         float* dbp = db_part + b0 * g_s;
-        if (Ci == 1) hipLaunchKernelGGL(k_first_block_bwd<1>, grid, dim3(kFbThreads), 0, s, g, mm, o, st, dwp, dbp, Co, H, W);
-        else if (Ci == 2) hipLaunchKernelGGL(k_first_block_bwd<2>, grid, dim3(kFbThreads), 0, s, g, mm, o, st, dwp, dbp, Co, H, W);
-        else hipLaunchKernelGGL(k_first_block_bwd<3>, grid, dim3(kFbThreads), 0, s, g, mm, o, st, dwp, dbp, Co, H, W);
+        if (Ci == 1) hipLaunchKernelGGL(k_first_block_bwd<1>, grid, dim3(kFbBwdThreads), 0, s, g, mm, o, st, dwp, dbp, Co, H, W);
+        else if (Ci == 2) hipLaunchKernelGGL(k_first_block_bwd<2>, grid, dim3(kFbBwdThreads), 0, s, g, mm, o, st, dwp, dbp, Co, H, W);
+        else hipLaunchKernelGGL(k_first_block_bwd<3>, grid, dim3(kFbBwdThreads), 0, s, g, mm, o, st, dwp, dbp, Co, H, W);
         AURPPO_LAUNCH_CHECK("k_first_block_bwd");
     }
     return AURPPO_OK;

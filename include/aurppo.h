@@ -274,7 +274,7 @@ int aurppo_weighted_batch_sum_f32(const float* x, const float* w, float* out, in
  * writes y, mask (B,Co,H/2,W/2) with K9's conventions.  Backward leaves, per (sample, group of 16 output channels),
  * partial sums dw_part (B*Co/16, 16, (Ci+1)*9) and db_part (B*Co/16, 16): summed over the first dimension and laid out
  * per channel they are the gradients of W (Co, Ci+1, 3, 3) and bias.  The input takes no gradient (it is data).  Co must
- * be a multiple of 16. */
+ * be a multiple of 16, W at least 3. */
 int aurppo_first_block_fwd_f32(const float* obs, const float* w, const float* bias, const float* state, float* y,
                                uint8_t* mask, int B, int Ci, int Co, int H, int W, void* stream);
 int aurppo_first_block_bwd_f32(const float* dy, const uint8_t* mask, const float* obs, const float* state,
