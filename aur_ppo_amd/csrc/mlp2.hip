@@ -22,6 +22,9 @@
 //   * at the end set 1 hands its accumulators to set 0 through LDS, so a workgroup still writes ONE slab.
 #include <stdlib.h>
 
+// The library is built with -ffp-contract=off for K1's bit parity; nothing in this file is held to bit parity (K7 is
+// checked to 1e-5 against fp32 autograd), so its VALU code may fuse a*b+c: 1.4 % off the kernel (profiles/r02/ab_fp_contract.txt).
+#pragma clang fp contract(fast)
 #include "mlp_common.h"
 
 using namespace aurppo_mlp;
