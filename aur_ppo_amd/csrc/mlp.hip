@@ -993,6 +993,15 @@ static int mlp_step_impl(const float* obs, const float* actions, const float* re
     return AURPPO_OK;
 }
 
+int aurppo_mlp::launch_mlp_reduce(const float* slabs, const double* loss_part, int n_slabs, int n_params, const PpoHyper& h,
+                                  float* grads, float* out_scalars, hipStream_t s) {
+    AURPPO_REQUIRE(n_slabs >= 1 && n_slabs <= kMaxGrid, AURPPO_ESHAPE, "launch_mlp_reduce: n_slabs=%d", n_slabs);
+    hipLaunchKernelGGL(k_mlp_reduce, dim3((n_params + 63) / 64), dim3(1024), 0, s, slabs, loss_part, n_slabs, n_params, h, grads,
+                       out_scalars, (double*)nullptr, (float*)nullptr, (unsigned*)nullptr);
+    AURPPO_LAUNCH_CHECK("k_mlp_reduce");
+    return AURPPO_OK;
+}
+
 extern "C" int aurppo_mlp_ppo_step_f32(const float* obs, const float* actions, const float* rec, const int32_t* idx,
                                        int M, int D, int A, int continuous, int hidden, const float* params, const int* layout_h,
                                        int n_params, float* grads, double clip, double ent_coef, double vf_coef,

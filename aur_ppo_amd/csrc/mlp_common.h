@@ -155,5 +155,8 @@ __device__ __forceinline__ f32x16 zero16() {
 // mlp2.hip: the two-tile-set variant of K7 (8 waves per workgroup); same arguments, same slab / loss_part outputs.
 size_t mlp_step2_lds_bytes();
 int launch_mlp_step2(const MlpArgs& a, int grid, hipStream_t s);
+// mlp.hip: k_mlp_reduce alone (grads[p] = fixed-order sum over n_slabs slabs, loss scalars folded) -- mlp_wide.hip's tail.
+int launch_mlp_reduce(const float* slabs, const double* loss_part, int n_slabs, int n_params, const PpoHyper& h, float* grads,
+                      float* out_scalars, hipStream_t s);
 
 }  // namespace aurppo_mlp

@@ -1,0 +1,766 @@
+// K7w / K8w: the fused PPO minibatch step (as K7, mlp.hip / mlp2.hip) and the rollout step (as K8) for every MLP
+// actor-critic the reference's CLI can ask for that is NOT the default 64-64 one: hidden_dim <= 128, num_layers 1..3,
+// state_dim <= 128 (src/nets/nets.py:19-53 builds `num_layers` Tanh layers of `hidden_dim`; flags src/run_ppo.py:33,37).
+// Same inputs, same outputs (per-workgroup gradient slabs + loss partials, folded by k_mlp_reduce; the optimizer
+// step is K6b's), same fp32 MFMA arithmetic -- what differs is where things live, because at 128 x 3 neither the
+// weights (2 x 192 KB) nor the weight-gradient accumulators (2 x 200 KB) of BOTH nets fit one CU:
+//   * a workgroup (4 waves, one per SIMD) works on ONE net: actor and critic share nothing but the input rows and the
+//     advantage statistics (the loss is a sum of an actor-only and a critic-only term), so even and odd workgroups
+//     take the two nets of the same row tiles and write disjoint halves of the same slab;
+//   * wave w owns the w-th 32-column block of every layer: its weight-gradient blocks (out-block 0..3, in-block w) of
+//     every layer stay in registers over the whole launch (13 accumulators of 16 registers at 128 x 3: the 512-register
+//     budget of one wave per SIMD is what makes that possible);
+//   * the weights are not staged in LDS: a preparation kernel lays every hidden layer out once per launch in MFMA
+//     B-operand order (forward: W^T blocks, backward: W blocks; zero-padded to 32-multiples), and a wave streams each
+//     32x32 block with four 16-byte loads per lane from L2, one block ahead of the MFMA chain that consumes it;
+//   * activations live in LDS ([32 rows][129]); dZ_l overwrites H_l in place (a wave only ever reads its own column
+//     block of H_l once dZ_l is being formed), so a layer costs one 16.5 KB buffer.
+// Not tuned like k_mlp_step2 (one tile set, static tile striding): it exists so that no supported shape drops to the
+// ~100-launch per-op path.  Measured against that path in DESIGN section 4.7b.
+#include <stdlib.h>
+
+#pragma clang fp contract(fast)
+#include "mlp_common.h"
+
+using namespace aurppo_mlp;
+
+namespace {
+
+constexpr int HPW = 128;            // widest (padded) layer
+constexpr int LDW = HPW + 1;        // LDS row stride of an activation matrix (odd: conflict-free row- and column-wise)
+constexpr int MAXL = 3;             // hidden layers
+constexpr int kOpBlk = 64 * 16;     // floats of one 32x32 block in operand order: [lane][16 k-steps]
+constexpr int kOpLayer = 16 * kOpBlk;                 // 4 x 4 blocks
+constexpr int kOpFloats = 2 * MAXL * 2 * kOpLayer;    // [net][layer][fwd | bwd]
+
+struct WideLayout {   // float offsets into the flat parameter / gradient bucket; layer NL is the head
+    int w[2][MAXL + 1], b[2][MAXL + 1];
+    int logstd, n_params;
+};
+
+struct WideArgs {
+    const float* obs;      // (B, D)
+    const float* actions;  // (B, AW) or nullptr (packed records)
+    const float4* rec;     // (B, 4) | (B, 16) packed
+    int rec_stride;
+    const int32_t* idx;    // (M,)
+    const float* params;
+    const float* wop;      // operand-order copies (k_mlpw_prep)
+    float* slabs;          // (pairs, n_params)
+    double* loss_part;     // (pairs, 8)
+    const double* stats;   // (n_stat_blocks, 2)
+    int n_stat_blocks;
+    int D, A, Hd, continuous;
+    WideLayout L;
+    PpoHyper h;
+    // rollout step
+    const float* noise;
+    float* out_actions;
+    float* out_logp;
+    float* out_value;
+    int N, net_base, net_count;
+};
+
+// stats[b] = partial (sum, sum of squares) of the minibatch's advantages; wop = every hidden layer of both nets in
+// operand order.  Forward copy, block (ob, kb): lane l, step m holds W[ob*32 + (l & 31)][kb*32 + 2m + (l >> 5)]
+// (B[k][j] = W[j][k]); backward copy, block (jb, kb): W[kb*32 + 2m + (l >> 5)][jb*32 + (l & 31)] (B[k][j] = W[k][j]).
+__global__ __launch_bounds__(256) void k_mlpw_prep(const float* __restrict__ params, WideLayout L, int NL, int D, int Hd,
+                                                   float* __restrict__ wop, const float4* __restrict__ rec, int rec_stride,
+                                                   const int32_t* __restrict__ idx, int M, double (*__restrict__ stats)[2],
+                                                   int n_stat_blocks) {
+    __shared__ double sc[2][4];
+    if ((int)blockIdx.x < n_stat_blocks) {
+        double s = 0.0, q = 0.0;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < M; i += n_stat_blocks * 256) {
+            const double a = (double)rec[(size_t)idx[i] * rec_stride].y;
+            s += a;
+            q += a * a;
+        }
+        const double bs = block_sum<4>(s, sc[0]);
+        const double bq = block_sum<4>(q, sc[1]);
+        if (threadIdx.x == 0) {
+            stats[blockIdx.x][0] = bs;
+            stats[blockIdx.x][1] = bq;
+        }
+        return;
+    }
+    const int b = blockIdx.x - n_stat_blocks, nb = gridDim.x - n_stat_blocks;
+    for (int e = b * 256 + threadIdx.x; e < kOpFloats; e += nb * 256) {
+        const int m = e & 15, lane = (e >> 4) & 63, blk = (e >> 10) & 15, dir = (e >> 14) & 1, nl = e >> 15;
+        const int n = nl / MAXL, l = nl - n * MAXL;
+        if (l >= NL || (dir == 1 && l == 0)) continue;
+        const int in_dim = l == 0 ? D : Hd;
+        const float* W = params + L.w[n][l];
+        const int hi = blk >> 2, kb = blk & 3;
+        int row, col;
+        if (dir == 0) {
+            row = hi * 32 + (lane & 31);
+            col = kb * 32 + 2 * m + (lane >> 5);
+        } else {
+            row = kb * 32 + 2 * m + (lane >> 5);
+            col = hi * 32 + (lane & 31);
+        }
+        wop[e] = (row < Hd && col < in_dim) ? W[row * in_dim + col] : 0.0f;
+    }
+}
+
+__device__ __forceinline__ const float* op_block(const float* wop, int net, int l, int dir, int hi, int kb, int lane) {
+    return wop + (size_t)((net * MAXL + l) * 2 + dir) * kOpLayer + (hi * 4 + kb) * kOpBlk + lane * 16;
+}
+
+__device__ __forceinline__ void load_b(float (&b)[16], const float* p) {
+    const float4* q = reinterpret_cast<const float4*>(p);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const float4 v = q[u];
+        b[4 * u + 0] = v.x; b[4 * u + 1] = v.y; b[4 * u + 2] = v.z; b[4 * u + 3] = v.w;
+    }
+}
+
+// acc += A(32 x 32) * B(32 x 32): A from LDS through a_at(i, k), B already in registers (operand order)
+template <class FA>
+__device__ __forceinline__ void mma_breg(f32x16& acc, FA a_at, const float (&b)[16], int lane) {
+    const int ij = lane & 31, kk = lane >> 5;
+    float av[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) av[m] = a_at(ij, 2 * m + kk);
+#pragma unroll
+    for (int m = 0; m < 16; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], b[m], acc, 0, 0, 0);
+}
+
+// One output block of a layer: acc = sum over nkb in-blocks of In[:, kb] * Wop[block (hi, kb)], the weight blocks
+// streamed one ahead.  In: [R][LDW] in LDS.
+__device__ __forceinline__ f32x16 stream_layer(const float* In, const float* wop, int net, int l, int dir, int hi, int nkb,
+                                               int lane) {
+    f32x16 acc = zero16();
+    float bq[2][16];
+    load_b(bq[0], op_block(wop, net, l, dir, hi, 0, lane));
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        if (kb < nkb) {
+            if (kb + 1 < nkb) load_b(bq[(kb + 1) & 1], op_block(wop, net, l, dir, hi, kb + 1, lane));
+            mma_breg(acc, [&](int i, int k) { return In[i * LDW + kb * 32 + k]; }, bq[kb & 1], lane);
+        }
+    }
+    return acc;
+}
+
+struct WideLds {
+    float* sX;            // [R][LDW]
+    float* sH[MAXL];      // [R][LDW] each; dZ_l overwrites H_l in the backward pass
+    float* sW3;           // [AP][LDW] head weights of this net, rows >= out_dim zero
+    float* sOut;          // [R][LDO] head outputs, then their gradients
+    float* sAct;          // [R][LDO]
+    float* sDls;          // [R][LDO] per-sample d logstd terms (actor)
+    float* sB;            // [MAXL][HPW] hidden biases, zero beyond Hd
+    float* sB3;           // [AP]
+    float* sLs;           // [AP]
+    float* sIvar;         // [AP]  1 / sigma^2 (step) | sigma (act)
+    float4* sRec;         // [R]
+    int* sSrc;            // [R]
+    int* sIdx;            // [2][R]
+};
+
+__device__ __forceinline__ WideLds carve(float* lds) {
+    WideLds s;
+    s.sX = lds;
+    for (int l = 0; l < MAXL; ++l) s.sH[l] = lds + (1 + l) * R * LDW;
+    s.sW3 = lds + (1 + MAXL) * R * LDW;
+    s.sOut = s.sW3 + AP * LDW;
+    s.sAct = s.sOut + R * LDO;
+    s.sDls = s.sAct + R * LDO;
+    s.sB = s.sDls + R * LDO;
+    s.sB3 = s.sB + MAXL * HPW;
+    s.sLs = s.sB3 + AP;
+    s.sIvar = s.sLs + AP;
+    s.sRec = reinterpret_cast<float4*>(s.sIvar + AP);   // every term above is a multiple of 4 floats
+    s.sSrc = reinterpret_cast<int*>(s.sRec + R);
+    s.sIdx = s.sSrc + R;
+    return s;
+}
+static_assert(((1 + MAXL) * R * LDW + AP * LDW + 3 * R * LDO + MAXL * HPW + 3 * AP) % 4 == 0, "sRec must be 16-B aligned");
+constexpr size_t wide_lds_bytes() {
+    return sizeof(float) * (size_t)((1 + MAXL) * R * LDW + AP * LDW + 3 * R * LDO + MAXL * HPW + 3 * AP + 4 * R + R + 2 * R);
+}
+
+// weights that stay in LDS: the head, every bias, log-std
+template <int NL>
+__device__ __forceinline__ void stage_small(const WideArgs& a, const WideLds& s, int net, bool act_mode) {
+    const int tid = threadIdx.x, Hd = a.Hd, out_dim = net == 0 ? a.A : 1;
+    for (int e = tid; e < R * LDW; e += kThreads) s.sX[e] = 0.0f;
+    for (int e = tid; e < AP * LDW; e += kThreads) {
+        const int o = e / LDW, i = e - o * LDW;
+        s.sW3[e] = (o < out_dim && i < Hd) ? a.params[a.L.w[net][NL] + o * Hd + i] : 0.0f;
+    }
+    for (int e = tid; e < NL * HPW; e += kThreads) {
+        const int l = e / HPW, c = e - l * HPW;
+        s.sB[e] = c < Hd ? a.params[a.L.b[net][l] + c] : 0.0f;
+    }
+    if (tid < AP) {
+        s.sB3[tid] = tid < out_dim ? a.params[a.L.b[net][NL] + tid] : 0.0f;
+        const float ls = (a.continuous && tid < a.A) ? a.params[a.L.logstd + tid] : 0.0f;
+        const float sd = expf(ls);
+        s.sLs[tid] = ls;
+        s.sIvar[tid] = act_mode ? sd : 1.0f / (sd * sd);
+    }
+    for (int e = tid; e < R * LDO; e += kThreads) s.sDls[e] = 0.0f;
+}
+
+// forward pass of one net over the tile in sX: H_1 .. H_NL, then the head into sOut (+ bias)
+template <int NL>
+__device__ __forceinline__ void forward_tile(const WideArgs& a, const WideLds& s, int net, int HB, int DB) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        if (w < HB) {
+            const float* In = l == 0 ? s.sX : s.sH[l - 1];
+            const f32x16 acc = stream_layer(In, a.wop, net, l, 0, w, l == 0 ? DB : HB, lane);
+            const int col = w * 32 + (lane & 31);
+            const float bias = s.sB[l * HPW + col];
+            float* Hl = s.sH[l];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) Hl[acc_row(e, lane) * LDW + col] = tanh_fast(acc[e] + bias);
+        }
+        __syncthreads();
+    }
+    if (w < 2) {   // head: 16 rows per wave as one 16x16 tile, K = HB blocks of 32
+        const float* Hin = s.sH[NL - 1] + w * 16 * LDW;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+            if (kb < HB)
+                acc += mma16<32>([&](int i, int k) { return Hin[i * LDW + kb * 32 + k]; },
+                                 [&](int k, int j) { return s.sW3[j * LDW + kb * 32 + k]; });
+        const int col = lane & 15;
+        const float bias = s.sB3[col];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s.sOut[(w * 16 + 4 * (lane >> 4) + e) * LDO + col] = acc[e] + bias;
+    }
+    __syncthreads();
+}
+
+template <int NL>
+__global__ __launch_bounds__(256) void k_mlpw_step(const WideArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const WideLds s = carve(lds);
+    __shared__ double s_red[2][kThreads / kWave];
+    __shared__ float s_mean, s_std;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int net = blockIdx.x & 1, pair = blockIdx.x >> 1, n_pairs = gridDim.x >> 1;
+    const int D = a.D, A = a.A, Hd = a.Hd;
+    const int HB = (Hd + 31) >> 5, DB = (D + 31) >> 5;
+    const int AW = a.continuous ? A : 1;
+    const int out_dim = net == 0 ? A : 1;
+    constexpr int CHW = NL == 3 ? 4 : 8;   // operand read-ahead of the LDS-fed chains: three layers of accumulators leave fewer registers
+
+    stage_small<NL>(a, s, net, false);
+    {
+        double sm = 0.0, q = 0.0;
+        for (int b = tid; b < a.n_stat_blocks; b += kThreads) {
+            sm += a.stats[2 * b];
+            q += a.stats[2 * b + 1];
+        }
+        const double ts = block_sum<kThreads / kWave>(sm, s_red[0]);
+        const double tq = block_sum<kThreads / kWave>(q, s_red[1]);
+        if (tid == 0) {
+            const double m = ts / (double)a.h.M;
+            double var = (tq - ts * m) / (double)(a.h.M - 1);
+            if (var < 0.0) var = 0.0;
+            s_mean = (float)m;
+            s_std = (float)sqrt(var);
+        }
+    }
+    __syncthreads();
+    const float mean = s_mean, denom = s_std + 1e-8f;
+    const float invM = 1.0f / (float)a.h.M;
+    const float g_ent = -a.h.ent_coef * invM;
+
+    // persistent accumulators: dW_l blocks (out-block ob, in-block w), head block (rows < AP, in-block w), bias columns
+    f32x16 gW[NL][4];
+#pragma unroll
+    for (int l = 0; l < NL; ++l)
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) gW[l][ob] = zero16();
+    f32x16 gW3 = zero16();
+    float gb[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) gb[l] = 0.0f;
+    double l_a = 0, l_b = 0, l_c = 0, l_d = 0, l_e = 0;   // actor: pg, ent, okl, kl, cf; critic: vl in l_a
+    float g_b3c = 0.0f, g_head = 0.0f;
+
+    const int n_tiles = (a.h.M + R - 1) / R;
+    // staging slots: 8 threads per row, columns (tid & 7) + 8u
+    const int x_r = tid >> 3, x_c0 = tid & 7;
+    float xr[16], ar[2];
+    float4 p_rec = make_float4(0.f, 0.f, 0.f, 0.f);
+    int p_src = -1, n_idx = -1;
+    auto load_idx = [&](int tile) -> int {
+        const int m = tile * R + tid;
+        return (tile < n_tiles && m < a.h.M) ? a.idx[m] : -1;
+    };
+    const float* const act_base = a.actions ? a.actions : reinterpret_cast<const float*>(a.rec) + 4;
+    const int act_stride = a.actions ? AW : 16;
+    auto prefetch = [&](const int* sidx) {
+        const int src = sidx[x_r];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int c = x_c0 + 8 * u;
+            xr[u] = (src >= 0 && c < D) ? a.obs[(size_t)src * D + c] : 0.0f;
+        }
+        if (net == 0) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int e = tid + u * kThreads, r = e >> 4, c = e & 15;
+                const int sa = sidx[r];
+                ar[u] = (sa >= 0 && c < AW) ? act_base[(size_t)sa * act_stride + c] : 0.0f;
+            }
+        }
+        if (tid < R) {
+            p_src = sidx[tid];
+            if (p_src >= 0) p_rec = a.rec[(size_t)p_src * a.rec_stride];
+        }
+    };
+    if (tid < R) {
+        s.sIdx[tid] = load_idx(pair);
+        s.sIdx[R + tid] = load_idx(pair + n_pairs);
+    }
+    __syncthreads();
+    prefetch(s.sIdx);
+    if (tid < R) n_idx = load_idx(pair + 2 * n_pairs);
+    int it = 0;
+    for (int tile = pair; tile < n_tiles; tile += n_pairs, ++it) {
+        // ---- land the prefetched tile, start fetching the next one
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int c = x_c0 + 8 * u;
+            if (c < D) s.sX[x_r * LDW + c] = xr[u];
+        }
+        if (net == 0) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int e = tid + u * kThreads;
+                s.sAct[(e >> 4) * LDO + (e & 15)] = ar[u];
+            }
+        }
+        if (tid < R) {
+            s.sSrc[tid] = p_src;
+            s.sRec[tid] = p_rec;
+            s.sIdx[(it & 1) * R + tid] = n_idx;
+        }
+        __syncthreads();
+        // the next tile's rows are fetched behind this tile's math -- except with three layers, whose accumulators leave
+        // no registers to hold them that long: there they are fetched at the end of the tile (latency exposed, ~5 %)
+        if (NL < 3) prefetch(s.sIdx + ((it + 1) & 1) * R);
+        if (tid < R) n_idx = load_idx(tile + 3 * n_pairs);
+
+        forward_tile<NL>(a, s, net, HB, DB);
+
+        // ---- loss lanes (one per row): this net's half of the PPO terms; head outputs become their gradients
+        if (tid < R) {
+            float* out = s.sOut + tid * LDO;
+            if (s.sSrc[tid] >= 0) {
+                const float4 rc = s.sRec[tid];
+                if (net == 1) {
+                    const PpoSample t = ppo_sample(rc.x, rc.x, rc.y, out[0], rc.w, rc.z, mean, denom, invM, a.h);
+                    l_a += t.vl;
+                    out[0] = t.g_v;
+                    g_b3c += t.g_v;
+                } else if (a.continuous) {
+                    const float* act = s.sAct + tid * LDO;
+                    float logp = 0.0f, ent = 0.0f;
+                    for (int k = 0; k < A; ++k) {
+                        const float ls = s.sLs[k];
+                        const float zk = act[k] - out[k];
+                        logp += (-(zk * zk) * (0.5f * s.sIvar[k]) - ls) - 0.9189385332046727f;
+                        ent += (0.5f + 0.9189385332046727f) + ls;
+                    }
+                    const PpoSample t = ppo_sample(logp, rc.x, rc.y, rc.w, rc.w, rc.z, mean, denom, invM, a.h);
+                    l_a += t.pg; l_b += ent; l_c += t.okl; l_d += t.kl; l_e += t.cf;
+                    for (int k = 0; k < A; ++k) {
+                        const float zk = act[k] - out[k];
+                        out[k] = t.g_logp * (zk * s.sIvar[k]);
+                        s.sDls[tid * LDO + k] = t.g_logp * (zk * zk * s.sIvar[k] - 1.0f) + g_ent;
+                    }
+                } else {
+                    const float* act = s.sAct + tid * LDO;
+                    float mx = out[0];
+                    for (int k = 1; k < A; ++k) mx = fmaxf(mx, out[k]);
+                    float se = 0.0f;
+                    for (int k = 0; k < A; ++k) se += expf(out[k] - mx);
+                    const float lse = mx + logf(se);
+                    const int ai = (int)act[0];
+                    float logp = 0.0f, ent = 0.0f;
+                    for (int k = 0; k < A; ++k) {
+                        const float lpk = out[k] - lse;
+                        ent -= expf(lpk) * lpk;
+                        if (k == ai) logp = lpk;
+                    }
+                    const PpoSample t = ppo_sample(logp, rc.x, rc.y, rc.w, rc.w, rc.z, mean, denom, invM, a.h);
+                    l_a += t.pg; l_b += ent; l_c += t.okl; l_d += t.kl; l_e += t.cf;
+                    for (int k = 0; k < A; ++k) {
+                        const float lpk = out[k] - lse;
+                        const float pk = expf(lpk);
+                        out[k] = t.g_logp * ((k == ai ? 1.0f : 0.0f) - pk) + g_ent * (-pk * (lpk + ent));
+                    }
+                }
+            } else {
+                for (int k = 0; k < AP; ++k) out[k] = s.sDls[tid * LDO + k] = 0.0f;
+            }
+        }
+        __syncthreads();
+
+        // ---- head backward: column sums (d b3, d logstd), dH_NL -> dZ_NL (in place), dW3
+        if (net == 0 && w == 3 && lane < 2 * AP) {
+            const float* src = lane < AP ? s.sOut + lane : s.sDls + (lane - AP);
+            float cs = 0.0f;
+#pragma unroll
+            for (int r = 0; r < R; ++r) cs += src[r * LDO];
+            g_head += cs;
+        }
+        if (w < HB) {
+            float* HL = s.sH[NL - 1];
+            f32x16 acc = zero16();
+            mma32<AP>(acc, [&](int i, int k) { return s.sOut[i * LDO + k]; },
+                      [&](int k, int j) { return s.sW3[k * LDW + w * 32 + j]; });
+            mma32<R, CHW>(gW3, [&](int i, int k) { return i < AP ? s.sOut[k * LDO + i] : 0.0f; },
+                          [&](int k, int j) { return HL[k * LDW + w * 32 + j]; }, lane);
+            const int col = w * 32 + (lane & 31);
+            float colsum = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float* hp = HL + acc_row(e, lane) * LDW + col;
+                const float h = *hp;
+                const float dz = acc[e] * (1.0f - h * h);
+                colsum += dz;
+                *hp = dz;
+            }
+            colsum += __shfl_xor(colsum, 32, kWave);
+            gb[NL - 1] += colsum;
+        }
+        __syncthreads();
+        // ---- hidden layers, top down: dW_l, dH_{l-1} -> dZ_{l-1} (in place)
+#pragma unroll
+        for (int l = NL - 1; l >= 1; --l) {
+            if (w < HB) {
+                const float* dZ = s.sH[l];
+                float* Hp = s.sH[l - 1];
+#pragma unroll
+                for (int ob = 0; ob < 4; ++ob)
+                    if (ob < HB)
+                        mma32<R, CHW>(gW[l][ob], [&](int i, int k) { return dZ[k * LDW + ob * 32 + i]; },
+                                      [&](int k, int j) { return Hp[k * LDW + w * 32 + j]; }, lane);
+                const f32x16 acc = stream_layer(dZ, a.wop, net, l, 1, w, HB, lane);
+                const int col = w * 32 + (lane & 31);
+                float colsum = 0.0f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float* hp = Hp + acc_row(e, lane) * LDW + col;
+                    const float h = *hp;
+                    const float dz = acc[e] * (1.0f - h * h);
+                    colsum += dz;
+                    *hp = dz;
+                }
+                colsum += __shfl_xor(colsum, 32, kWave);
+                gb[l - 1] += colsum;
+            }
+            __syncthreads();
+        }
+        // ---- dW_1 (in-block w of the state)
+        if (w < DB) {
+            const float* dZ = s.sH[0];
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob)
+                if (ob < HB)
+                    mma32<R, CHW>(gW[0][ob], [&](int i, int k) { return dZ[k * LDW + ob * 32 + i]; },
+                                  [&](int k, int j) { return s.sX[k * LDW + w * 32 + j]; }, lane);
+        }
+        if (NL >= 3) prefetch(s.sIdx + ((it + 1) & 1) * R);
+        __syncthreads();
+    }
+
+    // ---- this workgroup's half of the pair's slab
+    float* slab = a.slabs + (size_t)pair * a.L.n_params;
+    {
+        const int col = w * 32 + (lane & 31);
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            const int in_dim = l == 0 ? D : Hd;
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob) {
+                if (ob < HB && col < in_dim) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int o = ob * 32 + acc_row(e, lane);
+                        if (o < Hd) slab[a.L.w[net][l] + o * in_dim + col] = gW[l][ob][e];
+                    }
+                }
+            }
+            if (lane < 32 && col < Hd) slab[a.L.b[net][l] + col] = gb[l];
+        }
+        if (col < Hd) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int o = acc_row(e, lane);
+                if (o < out_dim) slab[a.L.w[net][NL] + o * Hd + col] = gW3[e];
+            }
+        }
+    }
+    if (net == 0 && w == 3) {
+        if (lane < A) slab[a.L.b[0][NL] + lane] = g_head;
+        if (a.continuous && lane >= AP && lane - AP < A) slab[a.L.logstd + lane - AP] = g_head;
+    }
+    if (w == 0) {
+        float c = lane < R ? g_b3c : 0.0f;
+        double v5[5] = {l_a, l_b, l_c, l_d, l_e};
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) c += __shfl_down(c, off, kWave);
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            double x = lane < R ? v5[q] : 0.0;
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) x += __shfl_down(x, off, kWave);
+            v5[q] = x;
+        }
+        if (lane == 0) {
+            double* lp = a.loss_part + (size_t)pair * 8;   // {pg, vl, ent, okl, kl, cf, mean, std}
+            if (net == 0) {
+                lp[0] = v5[0]; lp[2] = v5[1]; lp[3] = v5[2]; lp[4] = v5[3]; lp[5] = v5[4];
+            } else {
+                slab[a.L.b[1][NL]] = c;
+                lp[1] = v5[0];
+                lp[6] = (double)mean;
+                lp[7] = (double)s_std;
+            }
+        }
+    }
+}
+
+// K8w: policy.evaluate(next_obs) under no_grad + the three buffer row stores (src/ppo.py:103-108), or value only
+// (noise == nullptr, src/ppo.py:161).  Workgroup = (row tile, net).
+template <int NL>
+__global__ __launch_bounds__(256) void k_mlpw_act(const WideArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const WideLds s = carve(lds);
+    const int tid = threadIdx.x;
+    const int net = a.net_base + (int)(blockIdx.x % a.net_count), row0 = (int)(blockIdx.x / a.net_count) * R;
+    const int D = a.D, A = a.A, HB = (a.Hd + 31) >> 5, DB = (D + 31) >> 5;
+    stage_small<NL>(a, s, net, true);
+    __syncthreads();
+    {
+        const int r = tid >> 3, n = row0 + r;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int c = (tid & 7) + 8 * u;
+            if (c < D) s.sX[r * LDW + c] = n < a.N ? a.obs[(size_t)n * D + c] : 0.0f;
+        }
+    }
+    __syncthreads();
+    forward_tile<NL>(a, s, net, HB, DB);
+    if (tid >= R || row0 + tid >= a.N) return;
+    const int n = row0 + tid;
+    const float* mu = s.sOut + tid * LDO;
+    if (net == 1) {
+        a.out_value[n] = mu[0];
+        return;
+    }
+    if (!a.noise) return;
+    if (a.continuous) {
+        float lp = 0.0f;
+        for (int k = 0; k < A; ++k) {
+            const float ls = s.sLs[k], sd = s.sIvar[k];
+            const float act = mu[k] + sd * a.noise[(size_t)n * A + k];
+            a.out_actions[(size_t)n * A + k] = act;
+            const float z = act - mu[k];                               // as evaluate() forms it: (a - mu)
+            lp += (-(z * z) / (2.0f * (sd * sd)) - ls) - 0.9189385332046727f;
+        }
+        a.out_logp[n] = lp;
+    } else {
+        float mx = mu[0];
+        for (int k = 1; k < A; ++k) mx = fmaxf(mx, mu[k]);
+        float se = 0.0f;
+        for (int k = 0; k < A; ++k) se += expf(mu[k] - mx);
+        const float lse = mx + logf(se);
+        const float u = a.noise[n];
+        float cdf = 0.0f;
+        int pick = A - 1;
+        for (int k = 0; k < A; ++k) {
+            cdf += expf(mu[k] - lse);
+            if (u < cdf) {
+                pick = k;
+                break;
+            }
+        }
+        a.out_actions[n] = (float)pick;
+        a.out_logp[n] = mu[pick] - lse;
+    }
+}
+
+struct WideWs {
+    double* stats;       // (kStatBlocks, 2)
+    double* loss_part;   // (kMaxGrid / 2, 8)
+    float* wop;          // kOpFloats
+    float* slabs;        // (kMaxGrid / 2, n_params)
+};
+WideWs wide_ws(void* workspace) {
+    WideWs v;
+    char* p = reinterpret_cast<char*>(workspace);
+    v.stats = reinterpret_cast<double*>(p);
+    v.loss_part = v.stats + 2 * kStatBlocks;
+    v.wop = reinterpret_cast<float*>(v.loss_part + 8 * (kMaxGrid / 2));
+    v.slabs = v.wop + kOpFloats;
+    return v;
+}
+
+int fill_layout(WideLayout& L, const int* layout_h, int NL, int continuous, int n_params, const char* who) {
+    // layout_h: for net in (actor, critic): w_0, b_0, ..., w_NL, b_NL (layer NL = head); then logstd
+    const int per = 2 * (NL + 1);
+    for (int n = 0; n < 2; ++n)
+        for (int l = 0; l <= NL; ++l) {
+            L.w[n][l] = layout_h[n * per + 2 * l];
+            L.b[n][l] = layout_h[n * per + 2 * l + 1];
+        }
+    L.logstd = continuous ? layout_h[2 * per] : 0;
+    L.n_params = n_params;
+    for (int k = 0; k < 2 * per + (continuous ? 1 : 0); ++k)
+        AURPPO_REQUIRE(layout_h[k] >= 0 && layout_h[k] < n_params, AURPPO_ESHAPE, "%s: layout[%d]=%d", who, k, layout_h[k]);
+    return AURPPO_OK;
+}
+
+int check_shape(int D, int A, int continuous, int hidden, int num_layers, const char* who) {
+    AURPPO_REQUIRE(hidden >= 1 && hidden <= HPW, AURPPO_ESHAPE, "%s: hidden_dim=%d must be 1..%d", who, hidden, HPW);
+    AURPPO_REQUIRE(num_layers >= 1 && num_layers <= MAXL, AURPPO_ESHAPE, "%s: num_layers=%d must be 1..%d", who, num_layers, MAXL);
+    AURPPO_REQUIRE(D >= 1 && D <= HPW, AURPPO_ESHAPE, "%s: state_dim=%d must be 1..%d", who, D, HPW);
+    AURPPO_REQUIRE(A >= 1 && A <= AP && (continuous || A >= 2), AURPPO_ESHAPE,
+                   "%s: action_dim=%d must be 1..%d (>= 2 logits for a Categorical head)", who, A, AP);
+    return AURPPO_OK;
+}
+
+template <class K>
+int allow_lds(K kernel, bool* done) {
+    if (!*done) {
+        AURPPO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)wide_lds_bytes()));
+        *done = true;
+    }
+    return AURPPO_OK;
+}
+
+}  // namespace
+
+extern "C" size_t aurppo_mlp_wide_workspace_bytes(int n_params) {
+    return sizeof(double) * (2 * kStatBlocks + 8 * (kMaxGrid / 2)) + sizeof(float) * (size_t)kOpFloats +
+           sizeof(float) * (size_t)(kMaxGrid / 2) * (size_t)n_params + 64;
+}
+
+extern "C" int aurppo_mlp_wide_ppo_step_f32(const float* obs, const float* actions, const float* rec, const int32_t* idx, int M,
+                                            int D, int A, int continuous, int hidden, int num_layers, const float* params,
+                                            const int* layout_h, int n_params, float* grads, double clip, double ent_coef,
+                                            double vf_coef, int norm_adv, int vloss_mode, float* out_scalars, void* workspace,
+                                            void* stream, void* ev_begin, void* ev_end) {
+    const char* who = "aurppo_mlp_wide_ppo_step_f32";
+    AURPPO_REQUIRE(obs && rec && idx && params && layout_h && grads && out_scalars && workspace, AURPPO_EINVAL, "%s: null pointer", who);
+    AURPPO_REQUIRE(actions || (continuous ? A : 1) <= 12, AURPPO_ESHAPE,
+                   "%s: packed records hold at most 12 action floats (action_dim=%d)", who, A);
+    int rc = check_shape(D, A, continuous, hidden, num_layers, who);
+    if (rc != AURPPO_OK) return rc;
+    AURPPO_REQUIRE(M > 0 && n_params > 0, AURPPO_ESHAPE, "%s: M=%d n_params=%d", who, M, n_params);
+    AURPPO_REQUIRE(vloss_mode >= 0 && vloss_mode <= 2, AURPPO_EINVAL, "%s: bad vloss_mode %d", who, vloss_mode);
+    AURPPO_REQUIRE(aligned_to(workspace, 64) && aligned_to(rec, 16), AURPPO_EINVAL, "%s: workspace not 64-byte / rec not 16-byte aligned", who);
+    WideArgs a = {};
+    a.obs = obs; a.actions = actions; a.rec = reinterpret_cast<const float4*>(rec); a.rec_stride = actions ? 1 : 4;
+    a.idx = idx; a.params = params;
+    a.D = D; a.A = A; a.Hd = hidden; a.continuous = continuous ? 1 : 0;
+    rc = fill_layout(a.L, layout_h, num_layers, continuous, n_params, who);
+    if (rc != AURPPO_OK) return rc;
+    a.h = make_hyper(M, clip, ent_coef, vf_coef, norm_adv, vloss_mode);
+    const WideWs wv = wide_ws(workspace);
+    a.stats = wv.stats; a.loss_part = wv.loss_part; a.wop = wv.wop; a.slabs = wv.slabs;
+    hipStream_t s = (hipStream_t)stream;
+    int sb = (M + 1023) / 1024;
+    if (sb > kStatBlocks) sb = kStatBlocks;
+    a.n_stat_blocks = sb;
+    hipLaunchKernelGGL(k_mlpw_prep, dim3(sb + 96), dim3(256), 0, s, params, a.L, num_layers, D, hidden, wv.wop, a.rec,
+                       a.rec_stride, idx, M, reinterpret_cast<double (*)[2]>(wv.stats), sb);
+    AURPPO_LAUNCH_CHECK("k_mlpw_prep");
+    static int cus_of[kMaxDevices] = {0};
+    const int dslot = aurppo_device_slot();
+    if (!cus_of[dslot]) {
+        hipDeviceProp_t prop;
+        AURPPO_HIP_TRY(hipGetDeviceProperties(&prop, dslot));
+        cus_of[dslot] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : kMaxGrid;
+    }
+    const int n_tiles = (M + R - 1) / R;
+    int pairs = (cus_of[dslot] - 8) / 2;      // 8 CUs left to the shuffle kernels of the side stream, as K7
+    if (pairs > kMaxGrid / 2) pairs = kMaxGrid / 2;
+    if (pairs > n_tiles) pairs = n_tiles;
+    if (pairs < 1) pairs = 1;
+    static bool attr[kMaxDevices][MAXL] = {};
+    if (ev_begin) AURPPO_HIP_TRY(hipEventRecord((hipEvent_t)ev_begin, s));
+    switch (num_layers) {
+        case 1:
+            rc = allow_lds(k_mlpw_step<1>, &attr[dslot][0]);
+            if (rc != AURPPO_OK) return rc;
+            hipLaunchKernelGGL(k_mlpw_step<1>, dim3(2 * pairs), dim3(kThreads), wide_lds_bytes(), s, a);
+            break;
+        case 2:
+            rc = allow_lds(k_mlpw_step<2>, &attr[dslot][1]);
+            if (rc != AURPPO_OK) return rc;
+            hipLaunchKernelGGL(k_mlpw_step<2>, dim3(2 * pairs), dim3(kThreads), wide_lds_bytes(), s, a);
+            break;
+        default:
+            rc = allow_lds(k_mlpw_step<3>, &attr[dslot][2]);
+            if (rc != AURPPO_OK) return rc;
+            hipLaunchKernelGGL(k_mlpw_step<3>, dim3(2 * pairs), dim3(kThreads), wide_lds_bytes(), s, a);
+            break;
+    }
+    AURPPO_LAUNCH_CHECK("k_mlpw_step");
+    if (ev_end) AURPPO_HIP_TRY(hipEventRecord((hipEvent_t)ev_end, s));
+    return launch_mlp_reduce(wv.slabs, wv.loss_part, pairs, n_params, a.h, grads, out_scalars, s);
+}
+
+extern "C" int aurppo_mlp_wide_act_f32(const float* obs, const float* noise, int N, int D, int A, int continuous, int hidden,
+                                       int num_layers, const float* params, const int* layout_h, int n_params, float* actions,
+                                       float* logp, float* value, void* workspace, void* stream) {
+    const char* who = "aurppo_mlp_wide_act_f32";
+    AURPPO_REQUIRE(obs && params && layout_h && value && workspace, AURPPO_EINVAL, "%s: null pointer", who);
+    AURPPO_REQUIRE(!noise || (actions && logp), AURPPO_EINVAL, "%s: sampling needs actions and logp outputs", who);
+    int rc = check_shape(D, A, continuous, hidden, num_layers, who);
+    if (rc != AURPPO_OK) return rc;
+    AURPPO_REQUIRE(N > 0 && n_params > 0, AURPPO_ESHAPE, "%s: N=%d n_params=%d", who, N, n_params);
+    AURPPO_REQUIRE(aligned_to(workspace, 64), AURPPO_EINVAL, "%s: workspace not 64-byte aligned", who);
+    WideArgs a = {};
+    a.obs = obs; a.noise = noise; a.params = params; a.out_actions = actions; a.out_logp = logp; a.out_value = value;
+    a.N = N; a.D = D; a.A = A; a.Hd = hidden; a.continuous = continuous ? 1 : 0;
+    a.net_base = noise ? 0 : 1;
+    a.net_count = noise ? 2 : 1;
+    rc = fill_layout(a.L, layout_h, num_layers, continuous, n_params, who);
+    if (rc != AURPPO_OK) return rc;
+    const WideWs wv = wide_ws(workspace);
+    a.wop = wv.wop;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_mlpw_prep, dim3(96), dim3(256), 0, s, params, a.L, num_layers, D, hidden, wv.wop,
+                       (const float4*)nullptr, 0, (const int32_t*)nullptr, 0, (double (*)[2]) nullptr, 0);
+    AURPPO_LAUNCH_CHECK("k_mlpw_prep");
+    const int grid = ((N + R - 1) / R) * a.net_count;
+    static bool attr[kMaxDevices][MAXL] = {};
+    const int dslot = aurppo_device_slot();
+    switch (num_layers) {
+        case 1:
+            rc = allow_lds(k_mlpw_act<1>, &attr[dslot][0]);
+            if (rc != AURPPO_OK) return rc;
+            hipLaunchKernelGGL(k_mlpw_act<1>, dim3(grid), dim3(kThreads), wide_lds_bytes(), s, a);
+            break;
+        case 2:
+            rc = allow_lds(k_mlpw_act<2>, &attr[dslot][1]);
+            if (rc != AURPPO_OK) return rc;
+            hipLaunchKernelGGL(k_mlpw_act<2>, dim3(grid), dim3(kThreads), wide_lds_bytes(), s, a);
+            break;
+        default:
+            rc = allow_lds(k_mlpw_act<3>, &attr[dslot][2]);
+            if (rc != AURPPO_OK) return rc;
+            hipLaunchKernelGGL(k_mlpw_act<3>, dim3(grid), dim3(kThreads), wide_lds_bytes(), s, a);
+            break;
+    }
+    AURPPO_LAUNCH_CHECK("k_mlpw_act");
+    return AURPPO_OK;
+}

@@ -282,15 +282,22 @@ def ppo_loss(newlogp, newv, entropy, oldlogp, adv, oldv, ret, clip, ent_coef, vf
 MLP_HIDDEN, MLP_MAX_D, MLP_MAX_A = 64, 64, 16
 
 
+MLP_WIDE_MAX_HIDDEN, MLP_WIDE_MAX_D, MLP_WIDE_MAX_LAYERS = 128, 128, 3
+
+
 def mlp_layout(policy, bucket):
-    """Float offsets {w1,b1,w2,b2,w3,b3} x {actor, critic} + actor_logstd of ``policy`` (an
-    ``actor_critic`` with two hidden layers) inside ``bucket``'s flat buffers, or None if the policy
-    does not have the shape K7 is built for."""
-    if getattr(policy, "num_layers", None) != 2 or not hasattr(policy, "continuous"):
+    """Float offsets of ``policy`` (an ``actor_critic``: ``num_layers`` Tanh layers of ``hidden_dim``, src/nets/nets.py:19-53)
+    inside ``bucket``'s flat buffers, or None if no fused kernel is built for its shape.
+
+    The default shape (two layers of 64, D <= 64) gets K7/K8's layout {w1,b1,w2,b2,w3,b3} x {actor, critic} + actor_logstd;
+    every other shape up to three layers of 128 over D <= 128 gets K7w/K8w's (``wide=True``: {w_l, b_l} for l = 0..L per
+    net, then actor_logstd)."""
+    NL, Hd = getattr(policy, "num_layers", None), getattr(policy, "hidden_dim", None)
+    if not hasattr(policy, "continuous") or not isinstance(NL, int) or not isinstance(Hd, int):
+        return None
+    if not (1 <= NL <= MLP_WIDE_MAX_LAYERS and 1 <= Hd <= MLP_WIDE_MAX_HIDDEN):
         return None
     cont = bool(policy.continuous)
-    if getattr(policy, "hidden_dim", None) != MLP_HIDDEN:
-        return None
     off, pos = {}, 0
     for p in bucket.params:
         off[id(p)] = pos
@@ -298,25 +305,44 @@ def mlp_layout(policy, bucket):
     try:
         seq = []
         for net in (policy.actor.net, policy.critic.net):
-            for li in (0, 2, 4):
+            if len(net) != 2 * NL + 1:
+                return None
+            for li in range(0, 2 * NL + 1, 2):
                 seq += [off[id(net[li].weight)], off[id(net[li].bias)]]
         seq.append(off[id(policy.actor_logstd)] if cont else 0)
-    except (KeyError, AttributeError, IndexError):
+        D = policy.actor.net[0].weight.shape[1]
+        A = policy.actor.net[2 * NL].weight.shape[0]
+        for net, out in ((policy.actor.net, A), (policy.critic.net, 1)):
+            dims = [D] + [Hd] * NL + [out]
+            for l in range(NL + 1):
+                if tuple(net[2 * l].weight.shape) != (dims[l + 1], dims[l]):
+                    return None
+    except (KeyError, AttributeError, IndexError, TypeError):
         return None
-    D = policy.actor.net[0].weight.shape[1]
-    A = policy.actor.net[4].weight.shape[0]
-    if D > MLP_MAX_D or A > MLP_MAX_A or policy.critic.net[4].weight.shape[0] != 1 or (not cont and A < 2):
+    if A > MLP_MAX_A or (not cont and A < 2):
         return None
-    return dict(offsets=seq, n_params=pos, D=D, A=A, continuous=cont)
+    fast = NL == 2 and Hd == MLP_HIDDEN and D <= MLP_MAX_D
+    if not fast and D > MLP_WIDE_MAX_D:
+        return None
+    return dict(offsets=seq, n_params=pos, D=D, A=A, continuous=cont, hidden=Hd, num_layers=NL, wide=not fast)
 
 
 def mlp_step_flops(layout, M):
-    """Algorithmic FLOPs of one K7 launch (un-padded): forward of both nets, weight gradients of every
-    layer, input gradients of layers 2 and 3 (layer 1 needs none)."""
-    D, A, Hd = layout["D"], layout["A"], MLP_HIDDEN
-    fwd = (D * Hd + Hd * Hd + Hd * A) + (D * Hd + Hd * Hd + Hd)
-    bwd = fwd + (Hd * Hd + Hd * A) + (Hd * Hd + Hd)
-    return 2 * (fwd + bwd) * M
+    """Algorithmic FLOPs of one K7 / K7w launch (un-padded): forward of both nets, weight gradients of every
+    layer, input gradients of every layer but the first (which needs none)."""
+    D, A, Hd, NL = layout["D"], layout["A"], layout.get("hidden", MLP_HIDDEN), layout.get("num_layers", 2)
+    total = 0
+    for out in (A, 1):
+        dims = [D] + [Hd] * NL + [out]
+        mats = [dims[l] * dims[l + 1] for l in range(NL + 1)]
+        total += 2 * sum(mats) + sum(mats[1:])      # forward + dW of every layer, dX of layers 2..
+    return 2 * total * M
+
+
+def _wide_only_step(layout, who):
+    if layout.get("wide"):
+        raise ValueError(f"{who}: only the default 64-64 MLP has the chained minibatch kernels; this policy "
+                         f"({layout['num_layers']} x {layout['hidden']}) steps through mlp_ppo_step + clip_adam_")
 
 
 def pack_records(rec, actions, out=None):
@@ -359,6 +385,20 @@ def mlp_ppo_step(obs, actions, rec, idx, flat_param, layout, flat_grad, clip, en
         raise ValueError("mlp_ppo_step: buffer shapes do not match the policy")
     if out_scalars is None:
         out_scalars = torch.empty(N_SCALARS, dtype=torch.float32, device=obs.device)
+    if layout.get("wide"):
+        ws = _workspace("mlp_wide", lib.aurppo_mlp_wide_workspace_bytes(n), obs.device)
+        lay = (C.c_int * len(layout["offsets"]))(*layout["offsets"])
+        if events is not None:
+            for ev in events:
+                ev.record()
+        null = C.c_void_p(0)
+        _check(lib.aurppo_mlp_wide_ppo_step_f32(
+            _ptr(obs), _optr(actions), _ptr(rec), _ptr(idx, torch.int32), M, D, A, int(cont), layout["hidden"],
+            layout["num_layers"], _ptr(flat_param), lay, n, _ptr(flat_grad), float(clip), float(ent_coef), float(vf_coef),
+            int(bool(norm_adv)), int(vloss_mode), _ptr(out_scalars), C.c_void_p(ws.data_ptr()), _stream(),
+            C.c_void_p(events[0].cuda_event) if events is not None else null,
+            C.c_void_p(events[1].cuda_event) if events is not None else null), "aurppo_mlp_wide_ppo_step_f32")
+        return out_scalars
     ws = _workspace("mlp", lib.aurppo_mlp_workspace_bytes(n), obs.device)
     lay = (C.c_int * 13)(*layout["offsets"])
     args = (_ptr(obs), _optr(actions), _ptr(rec), _ptr(idx, torch.int32), M, D, A, int(cont), MLP_HIDDEN, _ptr(flat_param), lay, n,
@@ -385,6 +425,7 @@ def mlp_ppo_minibatch(obs, actions, rec, idx, flat_param, layout, flat_grad, cli
     cont = layout.get("continuous", True)
     if not _mlp_buffers_ok(obs, actions, rec, layout):
         raise ValueError("mlp_ppo_minibatch: buffer shapes do not match the policy")
+    _wide_only_step(layout, "mlp_ppo_minibatch")
     if min(flat_param.numel(), flat_grad.numel(), exp_avg.numel(), exp_avg_sq.numel()) < n:
         raise ValueError("mlp_ppo_minibatch: the flat bucket is smaller than the policy")
     # alignment padding past n_params is left alone: its gradient is never written, so clip and Adam are no-ops there
@@ -409,6 +450,7 @@ def mlp_ppo_grad(obs, actions, rec, idx, flat_param, layout, flat_grad, clip, en
     cont = layout.get("continuous", True)
     if not _mlp_buffers_ok(obs, actions, rec, layout):
         raise ValueError("mlp_ppo_grad: buffer shapes do not match the policy")
+    _wide_only_step(layout, "mlp_ppo_grad")
     ws = _workspace("mlp", lib.aurppo_mlp_workspace_bytes(n), obs.device)
     lay = (C.c_int * 13)(*layout["offsets"])
     _check(lib.aurppo_mlp_ppo_grad_f32(
@@ -426,6 +468,7 @@ def mlp_ppo_apply(flat_param, flat_grad, exp_avg, exp_avg_sq, layout, lr_dev, st
     n = layout["n_params"]
     if min(flat_param.numel(), flat_grad.numel(), exp_avg.numel(), exp_avg_sq.numel()) < n:
         raise ValueError("mlp_ppo_apply: the flat bucket is smaller than the policy")
+    _wide_only_step(layout, "mlp_ppo_apply")
     ws = _workspace("mlp", lib.aurppo_mlp_workspace_bytes(n), flat_param.device)
     lay = (C.c_int * 13)(*layout["offsets"])
     _check(lib.aurppo_mlp_ppo_apply_f32(
@@ -456,8 +499,17 @@ def mlp_act(obs, noise, flat_param, layout, actions=None, logp=None, value=None)
             raise ValueError("mlp_act: noise / output shapes do not match the policy")
     if obs.shape[-1] != D or value.numel() != N:
         raise ValueError("mlp_act: obs / value shapes do not match the policy")
-    lay = (C.c_int * 13)(*layout["offsets"])
     null = C.c_void_p(0)
+    if layout.get("wide"):
+        ws = _workspace("mlp_wide", lib.aurppo_mlp_wide_workspace_bytes(layout["n_params"]), dev)
+        lay = (C.c_int * len(layout["offsets"]))(*layout["offsets"])
+        _check(lib.aurppo_mlp_wide_act_f32(_ptr(obs), _ptr(noise) if noise is not None else null, N, D, A, int(cont),
+                                           layout["hidden"], layout["num_layers"], _ptr(flat_param), lay, layout["n_params"],
+                                           _ptr(actions) if noise is not None else null,
+                                           _ptr(logp) if noise is not None else null, _ptr(value),
+                                           C.c_void_p(ws.data_ptr()), _stream()), "aurppo_mlp_wide_act_f32")
+        return actions, logp, value
+    lay = (C.c_int * 13)(*layout["offsets"])
     _check(lib.aurppo_mlp_act_f32(_ptr(obs), _ptr(noise) if noise is not None else null, N, D, A, int(cont), MLP_HIDDEN,
                                   _ptr(flat_param), lay, layout["n_params"], _ptr(actions) if noise is not None else null,
                                   _ptr(logp) if noise is not None else null, _ptr(value), _stream()), "aurppo_mlp_act_f32")

@@ -383,11 +383,11 @@ class ppo(FlatAdamMixin):
         step = 0
         # single process, MLP policy, fused Adam over exactly the policy's bucket: K7 + clip + Adam chained, three
         # launches per minibatch (each call also prepares the statistics of the slice that follows it)
-        chain = (packed and self._mlp is not None and not self._dp and self._fused_adam
+        chain = (packed and self._mlp is not None and not self._mlp.get("wide") and not self._dp and self._fused_adam
                  and self._bucket_is_policy and hasattr(ops, "mlp_ppo_minibatch"))
         # one process per GPU: the same chain in two halves around the gradient all-reduce (SUM; the 1/W rides in the
         # apply kernel), three launches + one collective per minibatch
-        chain_dp = (packed and self._mlp is not None and self._dp and self._fused_adam
+        chain_dp = (packed and self._mlp is not None and not self._mlp.get("wide") and self._dp and self._fused_adam
                     and self._bucket_is_policy and hasattr(ops, "mlp_ppo_grad"))
         k7_act, k7_rec = (None, self._rec64) if (packed and self._rec64 is not None) else (b_actions, self._rec)
         starts = list(range(0, B, M))

@@ -230,6 +230,26 @@ int aurppo_mlp_act_f32(const float* obs, const float* noise, int N, int D, int A
                        const float* params, const int* layout_h, int n_params, float* actions, float* logp,
                        float* value, void* stream);
 
+/* ---- K7w / K8w: the same two operators for the other MLP shapes of the reference's CLI --------------------------------
+ * src/run_ppo.py:33,37 expose -d/--hidden_dim and -nl/--num_layers and src/nets/nets.py:19-53 builds any of them:
+ * `num_layers` (1..3) Tanh layers of `hidden` (1..128) units over a state of D (1..128) floats, A <= 16.  Same
+ * arguments and results as aurppo_mlp_ppo_step_ev_f32 / aurppo_mlp_act_f32 except
+ *   layout_h: for the actor, then the critic: {w_0, b_0, ..., w_L, b_L} (L = num_layers; layer L is the head), then
+ *             actor_logstd -- 4 * (num_layers + 1) + 1 float offsets into the bucket;
+ *   workspace: aurppo_mlp_wide_workspace_bytes(n_params) bytes, 64-byte aligned (the act entry point uses it for the
+ *             operand-order copy of the weights).
+ * ev_begin / ev_end (either may be NULL): hipEvent_t handles recorded around the main kernel.  The optimizer step that
+ * follows is aurppo_clip_adam_f32 (K6b).                                                                              */
+size_t aurppo_mlp_wide_workspace_bytes(int n_params);
+int aurppo_mlp_wide_ppo_step_f32(const float* obs, const float* actions, const float* rec, const int32_t* idx, int M,
+                                 int D, int A, int continuous, int hidden, int num_layers, const float* params,
+                                 const int* layout_h, int n_params, float* grads, double clip, double ent_coef,
+                                 double vf_coef, int norm_adv, int vloss_mode, float* out_scalars, void* workspace,
+                                 void* stream, void* ev_begin, void* ev_end);
+int aurppo_mlp_wide_act_f32(const float* obs, const float* noise, int N, int D, int A, int continuous, int hidden,
+                            int num_layers, const float* params, const int* layout_h, int n_params, float* actions,
+                            float* logp, float* value, void* workspace, void* stream);
+
 /* ---- K6: global-norm gradient clip over one flat bucket -------------------------------------
  * Replaces nn.utils.clip_grad_norm_(params, max_norm) (src/ppo.py:268; src/robot_ppo.py:401):
  * norm = ||g||_2, g *= min(1, max_norm / (norm + 1e-6)).  out_norm: 1 float (device), the

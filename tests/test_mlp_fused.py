@@ -88,7 +88,14 @@ def test_fused_step_rejects_unsupported_shapes():
     from aur_ppo_amd.actor_critic import actor_critic
     from aur_ppo_amd.flat import FlatBucket
     wide = actor_critic(64, (6,), 128, 2, 0.0, True).cuda()
-    assert H.mlp_layout(wide, FlatBucket(wide.parameters())) is None
+    wl = H.mlp_layout(wide, FlatBucket(wide.parameters()))
+    assert wl is not None and wl["wide"] and wl["hidden"] == 128          # K7w / K8w (tests/test_mlp_wide.py)
+    for shape in ((64, (6,), 256, 2), (64, (6,), 64, 4), (129, (6,), 128, 2), (8, (17,), 64, 2)):
+        pol2 = actor_critic(shape[0], shape[1], shape[2], shape[3], 0.0, True).cuda()
+        assert H.mlp_layout(pol2, FlatBucket(pol2.parameters())) is None, shape
+    with pytest.raises(ValueError):       # the chained minibatch kernels are the 64-64 shape's alone
+        H.mlp_ppo_grad(obs, act, rec, idx, bucket.flat_param, wl, bucket.flat_grad, 0.2, 0.0, 0.5, True, 1,
+                       torch.empty(9, device="cuda"), torch.zeros(1, device="cuda"))
 
 
 @pytest.mark.parametrize("T,N,D,A,M", [(8, 64, 4, 2, 200), (16, 64, 64, 16, 1024), (8, 64, 6, 11, 333), (8, 64, 5, 3, 200),
