@@ -12,7 +12,8 @@ unmodified, under in-memory alias modules:
 
 Fixtures are DATA (inputs + the reference's outputs); no reference source text is stored.
 
-    python oracle/gen_golden.py            # rewrites tests/golden/
+    python oracle/gen_golden.py                     # rewrites tests/golden/
+    python oracle/gen_golden.py trace evaluate      # only those fixture files
 """
 from __future__ import annotations
 
@@ -414,6 +415,13 @@ def gen_trace(ref_ppo):
         ("cfg4_normal_adv_tail_clipv", dict(obs_dim=3, continuous=True, act_dim=2, env_seed=8),
          dict(num_envs=5, num_steps=10, total_timesteps=3 * 50, continuous=True, gae=False, num_minibatches=4,
               clip_vloss=True, num_update_epochs=3)),
+        # the other net shapes of -d / -nl (src/run_ppo.py:33,37): what K7w / K8w are held to
+        ("cfg5_wide_128x3", dict(obs_dim=12, continuous=True, act_dim=3, env_seed=9),
+         dict(num_envs=8, num_steps=16, total_timesteps=3 * 128, continuous=True, num_minibatches=4, hidden_dim=128,
+              num_layers=3)),
+        ("cfg6_discrete_96x1", dict(obs_dim=6, continuous=False, act_dim=3, env_seed=10),
+         dict(num_envs=8, num_steps=32, total_timesteps=3 * 256, continuous=False, num_minibatches=4, hidden_dim=96,
+              num_layers=1)),
     ]
     for name, envc, over in cfgs:
         SynthVecEnv.current = envc
@@ -470,7 +478,10 @@ def gen_evaluate(ref_ac):
     names = []
     g = torch.Generator().manual_seed(99)
     for name, (D, A, cont, layers, hid) in {"cont_D64_A6": (64, 6, True, 2, 64), "disc_D4_A2": (4, 2, False, 2, 64),
-                                            "cont_D5_A3_L3": (5, 3, True, 3, 32)}.items():
+                                            "cont_D5_A3_L3": (5, 3, True, 3, 32),
+                                            "cont_D64_A6_H128_L3": (64, 6, True, 3, 128),
+                                            "disc_D8_A4_H128_L2": (8, 4, False, 2, 128),
+                                            "cont_D128_A6_H96_L1": (128, 6, True, 1, 96)}.items():
         torch.manual_seed(1)
         net = ref_ac(D, (A,) if cont else A, hid, layers, 0.0, cont)
         if cont:
@@ -540,13 +551,20 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)   # fixed reduction order for the recorded scalars
     ref_ppo, ref_ac = load_reference()
-    robot_gae = load_robot_gae()
-    gen_gae(ref_ppo, robot_gae)
-    gen_shuffle()
-    gen_loss(ref_ppo)
-    gen_trace(ref_ppo)
-    gen_evaluate(ref_ac)
-    gen_robot_eval()
+    only = set(sys.argv[1:])          # e.g. `gen_golden.py trace evaluate`: rewrite just those fixture files
+    want = lambda k: not only or k in only
+    if want("gae"):
+        gen_gae(ref_ppo, load_robot_gae())
+    if want("shuffle"):
+        gen_shuffle()
+    if want("loss"):
+        gen_loss(ref_ppo)
+    if want("trace"):
+        gen_trace(ref_ppo)
+    if want("evaluate"):
+        gen_evaluate(ref_ac)
+    if want("robot_eval"):
+        gen_robot_eval()
 
 
 if __name__ == "__main__":

@@ -153,14 +153,15 @@ def test_oracle_actor_critic_matches_reference_evaluate_and_init():
 
 
 # ------------------------------------------------------------------ whole update (src/ppo.py:192-292)
-@pytest.mark.parametrize("name", ["cfg1_discrete", "cfg2_continuous", "cfg3_normal_adv_tail", "cfg4_normal_adv_tail_clipv"])
+@pytest.mark.parametrize("name", ["cfg1_discrete", "cfg2_continuous", "cfg3_normal_adv_tail", "cfg4_normal_adv_tail_clipv",
+                                  "cfg5_wide_128x3", "cfg6_discrete_96x1"])
 def test_reference_update_restatement_reproduces_reference_train_trace(name):
     torch.set_num_threads(1)
     z = load("trace.npz")
     hp = dict(eval(str(z[f"{name}/params"])))
     init = {k[len(name) + 6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(f"{name}/init/")}
     D = init["actor.net.0.weight"].shape[1]
-    A = init["actor.net.4.weight"].shape[0]
+    A = init[f"actor.net.{2 * hp['num_layers']}.weight"].shape[0]
     cont = bool(hp["continuous"])
     net = O.make_actor_critic(D, (A,) if cont else A, hp["hidden_dim"], hp["num_layers"], cont)
     net.load_state_dict(init)

@@ -101,7 +101,7 @@ def _fixture_policy(name):
     return H, z, pol, bucket, lay, D, A, bool(cont)
 
 
-@pytest.mark.parametrize("name", ["cont_D64_A6", "disc_D4_A2"])
+@pytest.mark.parametrize("name", ["cont_D64_A6", "disc_D4_A2", "cont_D5_A3_L3", "cont_D64_A6_H128_L3", "disc_D8_A4_H128_L2", "cont_D128_A6_H96_L1"])
 def test_k8_value_only_matches_reference_value_fn(name):
     H, z, pol, bucket, lay, D, A, cont = _fixture_policy(name)
     obs = torch.from_numpy(z[f"{name}/obs"]).cuda()
@@ -109,7 +109,7 @@ def test_k8_value_only_matches_reference_value_fn(name):
     np.testing.assert_allclose(v.cpu().numpy(), z[f"{name}/value_fn"], rtol=1e-5, atol=2e-6)
 
 
-@pytest.mark.parametrize("name", ["cont_D64_A6", "disc_D4_A2"])
+@pytest.mark.parametrize("name", ["cont_D64_A6", "disc_D4_A2", "cont_D5_A3_L3", "cont_D64_A6_H128_L3", "disc_D8_A4_H128_L2", "cont_D128_A6_H96_L1"])
 def test_k8_sampled_logp_and_value_match_reference_formulas(name):
     """K8 with noise: the action it samples, evaluated by the oracle's restatement of ``evaluate`` with the fixture's
     weights (held to evaluate.npz by tests/test_oracle_golden.py), must give K8's log-prob and value."""
@@ -119,7 +119,8 @@ def test_k8_sampled_logp_and_value_match_reference_formulas(name):
     g = torch.Generator(device="cpu").manual_seed(5)
     noise = (torch.randn(37, A, generator=g) if cont else torch.rand(37, generator=g)).cuda()
     act, logp, v = H.mlp_act(obs, noise, bucket.flat_param, lay)
-    net = O.make_actor_critic(D, (A,) if cont else A, 64, 2, cont)
+    _, _, _, layers, hid = (int(x) for x in z[f"{name}/meta"])
+    net = O.make_actor_critic(D, (A,) if cont else A, hid, layers, cont)
     net.load_state_dict({k: torch.from_numpy(z[f"{name}/sd/{k}"]) for k in net.state_dict()})
     with torch.no_grad():
         a_cpu = act.cpu() if cont else act.cpu().long()
@@ -132,7 +133,7 @@ def test_k8_sampled_logp_and_value_match_reference_formulas(name):
     np.testing.assert_allclose(v.cpu().numpy(), v_o.view(-1).numpy(), rtol=1e-5, atol=2e-6)
 
 
-@pytest.mark.parametrize("name", ["cont_D64_A6", "disc_D4_A2"])
+@pytest.mark.parametrize("name", ["cont_D64_A6", "disc_D4_A2", "cont_D5_A3_L3", "cont_D64_A6_H128_L3", "disc_D8_A4_H128_L2", "cont_D128_A6_H96_L1"])
 def test_k7_forward_matches_reference_evaluate_per_sample(name):
     """K7 has no per-sample outputs; a minibatch of ONE sample exposes them: with old_logp = 0 the
     ``old_approx_kl`` scalar is -logp, ``entropy`` is the sample's entropy, and with the un-clipped value loss against
@@ -143,7 +144,7 @@ def test_k7_forward_matches_reference_evaluate_per_sample(name):
     B = obs.shape[0]
     rec = torch.zeros(B, 4, device="cuda")            # {old_logp, adv, ret, old_v} = 0
     rec[:, 1] = 1.0
-    b3c = lay["offsets"][11]                          # critic head bias
+    b3c = lay["offsets"][-2]                          # critic head bias (last entry before actor_logstd in both layouts)
     logp, ent, val = [], [], []
     g = torch.empty_like(bucket.flat_grad)
     for i in range(B):
@@ -158,7 +159,7 @@ def test_k7_forward_matches_reference_evaluate_per_sample(name):
     np.testing.assert_allclose(np.array(val), z[f"{name}/val"].reshape(-1), rtol=1e-5, atol=2e-6)
 
 
-@pytest.mark.parametrize("name", ["cont_D64_A6", "disc_D4_A2"])
+@pytest.mark.parametrize("name", ["cont_D64_A6", "disc_D4_A2", "cont_D5_A3_L3", "cont_D64_A6_H128_L3", "disc_D8_A4_H128_L2", "cont_D128_A6_H96_L1"])
 def test_k7_backward_matches_reference_autograd_gradients(name):
     """The fixture's gradients are the reference's own autograd of  sum(w*logp) + 0.3*sum(ent) + sum(val^2)  through
     ``actor_critic.evaluate``.  K7's loss becomes exactly that with old_logp = logp (ratio 1, inside the clip),

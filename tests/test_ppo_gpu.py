@@ -15,7 +15,7 @@ def _agent(hp):
 
 
 @pytest.mark.parametrize("name", ["cfg1_discrete", "cfg2_continuous", "cfg4_normal_adv_tail_clipv",
-                                  "cfg3_normal_adv_tail"])
+                                  "cfg3_normal_adv_tail", "cfg5_wide_128x3", "cfg6_discrete_96x1"])
 def test_gpu_update_reproduces_reference_trace(name):
     # cfg3 runs clip_vloss=False, where upstream regresses the critic to its OWN old values
     # (src/ppo.py:261): that gradient is rounding noise (value_loss ~1e-15) which Adam
@@ -27,8 +27,9 @@ def test_gpu_update_reproduces_reference_trace(name):
     hp = dict(eval(str(z[f"{name}/params"])))
     init = {k[len(name) + 6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(f"{name}/init/")}
     hp.update(gym_id="Synthetic-v0", obs_dim=init["actor.net.0.weight"].shape[1],
-              act_dim=init["actor.net.4.weight"].shape[0], log=False, save=False)
+              act_dim=init[f"actor.net.{2 * hp['num_layers']}.weight"].shape[0], log=False, save=False)
     agent = _agent(hp)
+    assert agent._mlp is not None and agent._mlp["wide"] == (name in ("cfg5_wide_128x3", "cfg6_discrete_96x1"))   # K7 / K7w, never the per-op path
     agent.policy.load_state_dict(init)
     agent.bucket.check_attached()
     agent.seed_all(1)

@@ -23,7 +23,7 @@ def _agent_from_trace(z, name):
     hp = dict(eval(str(z[f"{name}/params"])))
     init = {k[len(name) + 6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(f"{name}/init/")}
     D = init["actor.net.0.weight"].shape[1]
-    A = init["actor.net.4.weight"].shape[0]
+    A = init[f"actor.net.{2 * hp['num_layers']}.weight"].shape[0]
     hp.update(gym_id="Synthetic-v0", obs_dim=D, act_dim=A, log=False, save=False, device="cpu")
     agent = ppo(hp, ops=oracle_ops)
     agent.policy.load_state_dict(init)
@@ -51,7 +51,8 @@ def test_api_surface_matches_reference():
     assert b[0].data_ptr() == a.buffer.states.data_ptr()      # views, not copies
 
 
-@pytest.mark.parametrize("name", ["cfg1_discrete", "cfg2_continuous", "cfg3_normal_adv_tail", "cfg4_normal_adv_tail_clipv"])
+@pytest.mark.parametrize("name", ["cfg1_discrete", "cfg2_continuous", "cfg3_normal_adv_tail", "cfg4_normal_adv_tail_clipv",
+                                  "cfg5_wide_128x3", "cfg6_discrete_96x1"])
 def test_trainer_update_reproduces_reference_trace(name):
     torch.set_num_threads(1)
     z = load("trace.npz")
