@@ -161,27 +161,34 @@ struct WideLds {
     int* sIdx;            // [2][R]
 };
 
-__device__ __forceinline__ WideLds carve(float* lds) {
+// [sX][per-net block x nslots][sAct sDls sLs sIvar sRec sSrc sIdx]: one net per workgroup, or both (nslots = 2) when the
+// layers are at most 64 wide -- see k_mlpw_step
+constexpr int kNetFloats = MAXL * R * LDW + AP * LDW + R * LDO + MAXL * HPW + AP;
+constexpr int kTailFloats = 2 * R * LDO + 2 * AP;
+__device__ __forceinline__ WideLds carve(float* lds, int slot, int nslots) {
     WideLds s;
     s.sX = lds;
-    for (int l = 0; l < MAXL; ++l) s.sH[l] = lds + (1 + l) * R * LDW;
-    s.sW3 = lds + (1 + MAXL) * R * LDW;
+    float* nb = lds + R * LDW + slot * kNetFloats;
+    for (int l = 0; l < MAXL; ++l) s.sH[l] = nb + l * R * LDW;
+    s.sW3 = nb + MAXL * R * LDW;
     s.sOut = s.sW3 + AP * LDW;
-    s.sAct = s.sOut + R * LDO;
-    s.sDls = s.sAct + R * LDO;
-    s.sB = s.sDls + R * LDO;
+    s.sB = s.sOut + R * LDO;
     s.sB3 = s.sB + MAXL * HPW;
-    s.sLs = s.sB3 + AP;
+    float* tail = lds + R * LDW + nslots * kNetFloats;
+    s.sAct = tail;
+    s.sDls = s.sAct + R * LDO;
+    s.sLs = s.sDls + R * LDO;
     s.sIvar = s.sLs + AP;
     s.sRec = reinterpret_cast<float4*>(s.sIvar + AP);   // every term above is a multiple of 4 floats
     s.sSrc = reinterpret_cast<int*>(s.sRec + R);
     s.sIdx = s.sSrc + R;
     return s;
 }
-static_assert(((1 + MAXL) * R * LDW + AP * LDW + 3 * R * LDO + MAXL * HPW + 3 * AP) % 4 == 0, "sRec must be 16-B aligned");
-constexpr size_t wide_lds_bytes() {
-    return sizeof(float) * (size_t)((1 + MAXL) * R * LDW + AP * LDW + 3 * R * LDO + MAXL * HPW + 3 * AP + 4 * R + R + 2 * R);
+static_assert((R * LDW) % 4 == 0 && kNetFloats % 4 == 0 && kTailFloats % 4 == 0, "sRec must be 16-B aligned");
+constexpr size_t wide_lds_bytes(int nslots) {
+    return sizeof(float) * (size_t)(R * LDW + nslots * kNetFloats + kTailFloats + 4 * R + R + 2 * R);
 }
+static_assert(wide_lds_bytes(2) <= 160 * 1024, "both nets of a <= 64-wide policy must fit one CU's LDS");
 
 // weights that stay in LDS: the head, every bias, log-std
 template <int NL>
@@ -208,14 +215,14 @@ __device__ __forceinline__ void stage_small(const WideArgs& a, const WideLds& s,
 
 // forward pass of one net over the tile in sX: H_1 .. H_NL, then the head into sOut (+ bias)
 template <int NL>
-__device__ __forceinline__ void forward_tile(const WideArgs& a, const WideLds& s, int net, int HB, int DB) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+__device__ __forceinline__ void forward_tile(const WideArgs& a, const WideLds& s, int net, int cb, int HB, int DB) {
+    const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
-        if (w < HB) {
+        if (cb < HB) {
             const float* In = l == 0 ? s.sX : s.sH[l - 1];
-            const f32x16 acc = stream_layer(In, a.wop, net, l, 0, w, l == 0 ? DB : HB, lane);
-            const int col = w * 32 + (lane & 31);
+            const f32x16 acc = stream_layer(In, a.wop, net, l, 0, cb, l == 0 ? DB : HB, lane);
+            const int col = cb * 32 + (lane & 31);
             const float bias = s.sB[l * HPW + col];
             float* Hl = s.sH[l];
 #pragma unroll
@@ -223,8 +230,8 @@ __device__ __forceinline__ void forward_tile(const WideArgs& a, const WideLds& s
         }
         __syncthreads();
     }
-    if (w < 2) {   // head: 16 rows per wave as one 16x16 tile, K = HB blocks of 32
-        const float* Hin = s.sH[NL - 1] + w * 16 * LDW;
+    if (cb < 2) {   // head: 16 rows per wave as one 16x16 tile, K = HB blocks of 32
+        const float* Hin = s.sH[NL - 1] + cb * 16 * LDW;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb)
@@ -234,26 +241,37 @@ __device__ __forceinline__ void forward_tile(const WideArgs& a, const WideLds& s
         const int col = lane & 15;
         const float bias = s.sB3[col];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) s.sOut[(w * 16 + 4 * (lane >> 4) + e) * LDO + col] = acc[e] + bias;
+        for (int e = 0; e < 4; ++e) s.sOut[(cb * 16 + 4 * (lane >> 4) + e) * LDO + col] = acc[e] + bias;
     }
     __syncthreads();
 }
 
-template <int NL>
+// DUAL = false: a workgroup is one net (blockIdx & 1), wave w owns column block w (layers up to 128 wide).
+// DUAL = true (layers and state at most 64 wide, i.e. two column blocks): a workgroup is BOTH nets of its tiles -- waves
+// 0,1 the actor's two column blocks, waves 2,3 the critic's -- so no wave idles and a tile's rows are fetched once.
+template <int NL, bool DUAL>
 __global__ __launch_bounds__(256) void k_mlpw_step(const WideArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const WideLds s = carve(lds);
     __shared__ double s_red[2][kThreads / kWave];
     __shared__ float s_mean, s_std;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int net = blockIdx.x & 1, pair = blockIdx.x >> 1, n_pairs = gridDim.x >> 1;
+    const int net = DUAL ? (w >> 1) : (int)(blockIdx.x & 1), cb = DUAL ? (w & 1) : w;
+    const int pair = DUAL ? (int)blockIdx.x : (int)(blockIdx.x >> 1), n_pairs = DUAL ? (int)gridDim.x : (int)(gridDim.x >> 1);
+    const WideLds s = carve(lds, DUAL ? net : 0, DUAL ? 2 : 1);
+    const int hw = DUAL ? 1 : 3;          // the actor wave that also forms the head-side column sums
+    const int lrow = DUAL ? (tid & 127) : tid;   // loss lanes: the first 32 lanes of each net's first wave
     const int D = a.D, A = a.A, Hd = a.Hd;
     const int HB = (Hd + 31) >> 5, DB = (D + 31) >> 5;
     const int AW = a.continuous ? A : 1;
     const int out_dim = net == 0 ? A : 1;
     constexpr int CHW = NL == 3 ? 4 : 8;   // operand read-ahead of the LDS-fed chains: three layers of accumulators leave fewer registers
 
-    stage_small<NL>(a, s, net, false);
+    if (DUAL) {
+        stage_small<NL>(a, carve(lds, 0, 2), 0, false);
+        stage_small<NL>(a, carve(lds, 1, 2), 1, false);
+    } else {
+        stage_small<NL>(a, s, net, false);
+    }
     {
         double sm = 0.0, q = 0.0;
         for (int b = tid; b < a.n_stat_blocks; b += kThreads) {
@@ -276,11 +294,12 @@ __global__ __launch_bounds__(256) void k_mlpw_step(const WideArgs a) {
     const float g_ent = -a.h.ent_coef * invM;
 
     // persistent accumulators: dW_l blocks (out-block ob, in-block w), head block (rows < AP, in-block w), bias columns
-    f32x16 gW[NL][4];
+    constexpr int OBN = DUAL ? 2 : 4;   // out-blocks a layer can have
+    f32x16 gW[NL][OBN];
 #pragma unroll
     for (int l = 0; l < NL; ++l)
 #pragma unroll
-        for (int ob = 0; ob < 4; ++ob) gW[l][ob] = zero16();
+        for (int ob = 0; ob < OBN; ++ob) gW[l][ob] = zero16();
     f32x16 gW3 = zero16();
     float gb[NL];
 #pragma unroll
@@ -307,7 +326,7 @@ __global__ __launch_bounds__(256) void k_mlpw_step(const WideArgs a) {
             const int c = x_c0 + 8 * u;
             xr[u] = (src >= 0 && c < D) ? a.obs[(size_t)src * D + c] : 0.0f;
         }
-        if (net == 0) {
+        if (DUAL || net == 0) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int e = tid + u * kThreads, r = e >> 4, c = e & 15;
@@ -335,7 +354,7 @@ __global__ __launch_bounds__(256) void k_mlpw_step(const WideArgs a) {
             const int c = x_c0 + 8 * u;
             if (c < D) s.sX[x_r * LDW + c] = xr[u];
         }
-        if (net == 0) {
+        if (DUAL || net == 0) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int e = tid + u * kThreads;
@@ -353,20 +372,20 @@ __global__ __launch_bounds__(256) void k_mlpw_step(const WideArgs a) {
         if (NL < 3) prefetch(s.sIdx + ((it + 1) & 1) * R);
         if (tid < R) n_idx = load_idx(tile + 3 * n_pairs);
 
-        forward_tile<NL>(a, s, net, HB, DB);
+        forward_tile<NL>(a, s, net, cb, HB, DB);
 
         // ---- loss lanes (one per row): this net's half of the PPO terms; head outputs become their gradients
-        if (tid < R) {
-            float* out = s.sOut + tid * LDO;
-            if (s.sSrc[tid] >= 0) {
-                const float4 rc = s.sRec[tid];
+        if (lrow < R) {
+            float* out = s.sOut + lrow * LDO;
+            if (s.sSrc[lrow] >= 0) {
+                const float4 rc = s.sRec[lrow];
                 if (net == 1) {
                     const PpoSample t = ppo_sample(rc.x, rc.x, rc.y, out[0], rc.w, rc.z, mean, denom, invM, a.h);
                     l_a += t.vl;
                     out[0] = t.g_v;
                     g_b3c += t.g_v;
                 } else if (a.continuous) {
-                    const float* act = s.sAct + tid * LDO;
+                    const float* act = s.sAct + lrow * LDO;
                     float logp = 0.0f, ent = 0.0f;
                     for (int k = 0; k < A; ++k) {
                         const float ls = s.sLs[k];
@@ -379,10 +398,10 @@ __global__ __launch_bounds__(256) void k_mlpw_step(const WideArgs a) {
                     for (int k = 0; k < A; ++k) {
                         const float zk = act[k] - out[k];
                         out[k] = t.g_logp * (zk * s.sIvar[k]);
-                        s.sDls[tid * LDO + k] = t.g_logp * (zk * zk * s.sIvar[k] - 1.0f) + g_ent;
+                        s.sDls[lrow * LDO + k] = t.g_logp * (zk * zk * s.sIvar[k] - 1.0f) + g_ent;
                     }
                 } else {
-                    const float* act = s.sAct + tid * LDO;
+                    const float* act = s.sAct + lrow * LDO;
                     float mx = out[0];
                     for (int k = 1; k < A; ++k) mx = fmaxf(mx, out[k]);
                     float se = 0.0f;
@@ -404,27 +423,27 @@ __global__ __launch_bounds__(256) void k_mlpw_step(const WideArgs a) {
                     }
                 }
             } else {
-                for (int k = 0; k < AP; ++k) out[k] = s.sDls[tid * LDO + k] = 0.0f;
+                for (int k = 0; k < AP; ++k) out[k] = s.sDls[lrow * LDO + k] = 0.0f;
             }
         }
         __syncthreads();
 
         // ---- head backward: column sums (d b3, d logstd), dH_NL -> dZ_NL (in place), dW3
-        if (net == 0 && w == 3 && lane < 2 * AP) {
+        if (net == 0 && w == hw && lane < 2 * AP) {
             const float* src = lane < AP ? s.sOut + lane : s.sDls + (lane - AP);
             float cs = 0.0f;
 #pragma unroll
             for (int r = 0; r < R; ++r) cs += src[r * LDO];
             g_head += cs;
         }
-        if (w < HB) {
+        if (cb < HB) {
             float* HL = s.sH[NL - 1];
             f32x16 acc = zero16();
             mma32<AP>(acc, [&](int i, int k) { return s.sOut[i * LDO + k]; },
-                      [&](int k, int j) { return s.sW3[k * LDW + w * 32 + j]; });
+                      [&](int k, int j) { return s.sW3[k * LDW + cb * 32 + j]; });
             mma32<R, CHW>(gW3, [&](int i, int k) { return i < AP ? s.sOut[k * LDO + i] : 0.0f; },
-                          [&](int k, int j) { return HL[k * LDW + w * 32 + j]; }, lane);
-            const int col = w * 32 + (lane & 31);
+                          [&](int k, int j) { return HL[k * LDW + cb * 32 + j]; }, lane);
+            const int col = cb * 32 + (lane & 31);
             float colsum = 0.0f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -441,16 +460,16 @@ __global__ __launch_bounds__(256) void k_mlpw_step(const WideArgs a) {
         // ---- hidden layers, top down: dW_l, dH_{l-1} -> dZ_{l-1} (in place)
 #pragma unroll
         for (int l = NL - 1; l >= 1; --l) {
-            if (w < HB) {
+            if (cb < HB) {
                 const float* dZ = s.sH[l];
                 float* Hp = s.sH[l - 1];
 #pragma unroll
-                for (int ob = 0; ob < 4; ++ob)
+                for (int ob = 0; ob < OBN; ++ob)
                     if (ob < HB)
                         mma32<R, CHW>(gW[l][ob], [&](int i, int k) { return dZ[k * LDW + ob * 32 + i]; },
-                                      [&](int k, int j) { return Hp[k * LDW + w * 32 + j]; }, lane);
-                const f32x16 acc = stream_layer(dZ, a.wop, net, l, 1, w, HB, lane);
-                const int col = w * 32 + (lane & 31);
+                                      [&](int k, int j) { return Hp[k * LDW + cb * 32 + j]; }, lane);
+                const f32x16 acc = stream_layer(dZ, a.wop, net, l, 1, cb, HB, lane);
+                const int col = cb * 32 + (lane & 31);
                 float colsum = 0.0f;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
@@ -466,13 +485,13 @@ __global__ __launch_bounds__(256) void k_mlpw_step(const WideArgs a) {
             __syncthreads();
         }
         // ---- dW_1 (in-block w of the state)
-        if (w < DB) {
+        if (cb < DB) {
             const float* dZ = s.sH[0];
 #pragma unroll
-            for (int ob = 0; ob < 4; ++ob)
+            for (int ob = 0; ob < OBN; ++ob)
                 if (ob < HB)
                     mma32<R, CHW>(gW[0][ob], [&](int i, int k) { return dZ[k * LDW + ob * 32 + i]; },
-                                  [&](int k, int j) { return s.sX[k * LDW + w * 32 + j]; }, lane);
+                                  [&](int k, int j) { return s.sX[k * LDW + cb * 32 + j]; }, lane);
         }
         if (NL >= 3) prefetch(s.sIdx + ((it + 1) & 1) * R);
         __syncthreads();
@@ -481,12 +500,12 @@ __global__ __launch_bounds__(256) void k_mlpw_step(const WideArgs a) {
     // ---- this workgroup's half of the pair's slab
     float* slab = a.slabs + (size_t)pair * a.L.n_params;
     {
-        const int col = w * 32 + (lane & 31);
+        const int col = cb * 32 + (lane & 31);
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
             const int in_dim = l == 0 ? D : Hd;
 #pragma unroll
-            for (int ob = 0; ob < 4; ++ob) {
+            for (int ob = 0; ob < OBN; ++ob) {
                 if (ob < HB && col < in_dim) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
@@ -505,11 +524,11 @@ __global__ __launch_bounds__(256) void k_mlpw_step(const WideArgs a) {
             }
         }
     }
-    if (net == 0 && w == 3) {
+    if (net == 0 && w == hw) {
         if (lane < A) slab[a.L.b[0][NL] + lane] = g_head;
         if (a.continuous && lane >= AP && lane - AP < A) slab[a.L.logstd + lane - AP] = g_head;
     }
-    if (w == 0) {
+    if (cb == 0) {
         float c = lane < R ? g_b3c : 0.0f;
         double v5[5] = {l_a, l_b, l_c, l_d, l_e};
 #pragma unroll
@@ -540,7 +559,7 @@ __global__ __launch_bounds__(256) void k_mlpw_step(const WideArgs a) {
 template <int NL>
 __global__ __launch_bounds__(256) void k_mlpw_act(const WideArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const WideLds s = carve(lds);
+    const WideLds s = carve(lds, 0, 1);
     const int tid = threadIdx.x;
     const int net = a.net_base + (int)(blockIdx.x % a.net_count), row0 = (int)(blockIdx.x / a.net_count) * R;
     const int D = a.D, A = a.A, HB = (a.Hd + 31) >> 5, DB = (D + 31) >> 5;
@@ -555,7 +574,7 @@ __global__ __launch_bounds__(256) void k_mlpw_act(const WideArgs a) {
         }
     }
     __syncthreads();
-    forward_tile<NL>(a, s, net, HB, DB);
+    forward_tile<NL>(a, s, net, tid >> 6, HB, DB);
     if (tid >= R || row0 + tid >= a.N) return;
     const int n = row0 + tid;
     const float* mu = s.sOut + tid * LDO;
@@ -597,16 +616,16 @@ __global__ __launch_bounds__(256) void k_mlpw_act(const WideArgs a) {
 
 struct WideWs {
     double* stats;       // (kStatBlocks, 2)
-    double* loss_part;   // (kMaxGrid / 2, 8)
+    double* loss_part;   // (kMaxGrid, 8)
     float* wop;          // kOpFloats
-    float* slabs;        // (kMaxGrid / 2, n_params)
+    float* slabs;        // (kMaxGrid, n_params)
 };
 WideWs wide_ws(void* workspace) {
     WideWs v;
     char* p = reinterpret_cast<char*>(workspace);
     v.stats = reinterpret_cast<double*>(p);
     v.loss_part = v.stats + 2 * kStatBlocks;
-    v.wop = reinterpret_cast<float*>(v.loss_part + 8 * (kMaxGrid / 2));
+    v.wop = reinterpret_cast<float*>(v.loss_part + 8 * kMaxGrid);
     v.slabs = v.wop + kOpFloats;
     return v;
 }
@@ -636,20 +655,21 @@ int check_shape(int D, int A, int continuous, int hidden, int num_layers, const 
 }
 
 template <class K>
-int allow_lds(K kernel, bool* done) {
-    if (!*done) {
+int launch_wide(K kernel, bool* attr_done, int grid, int nslots, hipStream_t s, const WideArgs& a) {
+    if (!*attr_done) {
         AURPPO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)wide_lds_bytes()));
-        *done = true;
+                                           (int)wide_lds_bytes(nslots)));
+        *attr_done = true;
     }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kThreads), wide_lds_bytes(nslots), s, a);
     return AURPPO_OK;
 }
 
 }  // namespace
 
 extern "C" size_t aurppo_mlp_wide_workspace_bytes(int n_params) {
-    return sizeof(double) * (2 * kStatBlocks + 8 * (kMaxGrid / 2)) + sizeof(float) * (size_t)kOpFloats +
-           sizeof(float) * (size_t)(kMaxGrid / 2) * (size_t)n_params + 64;
+    return sizeof(double) * (2 * kStatBlocks + 8 * kMaxGrid) + sizeof(float) * (size_t)kOpFloats +
+           sizeof(float) * (size_t)kMaxGrid * (size_t)n_params + 64;
 }
 
 extern "C" int aurppo_mlp_wide_ppo_step_f32(const float* obs, const float* actions, const float* rec, const int32_t* idx, int M,
@@ -690,29 +710,25 @@ extern "C" int aurppo_mlp_wide_ppo_step_f32(const float* obs, const float* actio
         cus_of[dslot] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : kMaxGrid;
     }
     const int n_tiles = (M + R - 1) / R;
-    int pairs = (cus_of[dslot] - 8) / 2;      // 8 CUs left to the shuffle kernels of the side stream, as K7
-    if (pairs > kMaxGrid / 2) pairs = kMaxGrid / 2;
+    // layers and state at most two 32-column blocks wide: one workgroup carries both nets (k_mlpw_step<., true>)
+    const bool dual = hidden <= 64 && D <= 64;
+    int pairs = dual ? cus_of[dslot] - 8 : (cus_of[dslot] - 8) / 2;      // 8 CUs left to the side stream's shuffle kernels, as K7
+    if (pairs > (dual ? kMaxGrid : kMaxGrid / 2)) pairs = dual ? kMaxGrid : kMaxGrid / 2;
     if (pairs > n_tiles) pairs = n_tiles;
     if (pairs < 1) pairs = 1;
-    static bool attr[kMaxDevices][MAXL] = {};
+    static bool attr[kMaxDevices][2][MAXL] = {};
     if (ev_begin) AURPPO_HIP_TRY(hipEventRecord((hipEvent_t)ev_begin, s));
-    switch (num_layers) {
-        case 1:
-            rc = allow_lds(k_mlpw_step<1>, &attr[dslot][0]);
-            if (rc != AURPPO_OK) return rc;
-            hipLaunchKernelGGL(k_mlpw_step<1>, dim3(2 * pairs), dim3(kThreads), wide_lds_bytes(), s, a);
-            break;
-        case 2:
-            rc = allow_lds(k_mlpw_step<2>, &attr[dslot][1]);
-            if (rc != AURPPO_OK) return rc;
-            hipLaunchKernelGGL(k_mlpw_step<2>, dim3(2 * pairs), dim3(kThreads), wide_lds_bytes(), s, a);
-            break;
-        default:
-            rc = allow_lds(k_mlpw_step<3>, &attr[dslot][2]);
-            if (rc != AURPPO_OK) return rc;
-            hipLaunchKernelGGL(k_mlpw_step<3>, dim3(2 * pairs), dim3(kThreads), wide_lds_bytes(), s, a);
-            break;
+    const int grid = dual ? pairs : 2 * pairs;
+    bool* ad = &attr[dslot][dual ? 1 : 0][num_layers - 1];
+    switch (num_layers * 2 + (dual ? 1 : 0)) {
+        case 2: rc = launch_wide(k_mlpw_step<1, false>, ad, grid, 1, s, a); break;
+        case 3: rc = launch_wide(k_mlpw_step<1, true>, ad, grid, 2, s, a); break;
+        case 4: rc = launch_wide(k_mlpw_step<2, false>, ad, grid, 1, s, a); break;
+        case 5: rc = launch_wide(k_mlpw_step<2, true>, ad, grid, 2, s, a); break;
+        case 6: rc = launch_wide(k_mlpw_step<3, false>, ad, grid, 1, s, a); break;
+        default: rc = launch_wide(k_mlpw_step<3, true>, ad, grid, 2, s, a); break;
     }
+    if (rc != AURPPO_OK) return rc;
     AURPPO_LAUNCH_CHECK("k_mlpw_step");
     if (ev_end) AURPPO_HIP_TRY(hipEventRecord((hipEvent_t)ev_end, s));
     return launch_mlp_reduce(wv.slabs, wv.loss_part, pairs, n_params, a.h, grads, out_scalars, s);
@@ -743,24 +759,13 @@ extern "C" int aurppo_mlp_wide_act_f32(const float* obs, const float* noise, int
     AURPPO_LAUNCH_CHECK("k_mlpw_prep");
     const int grid = ((N + R - 1) / R) * a.net_count;
     static bool attr[kMaxDevices][MAXL] = {};
-    const int dslot = aurppo_device_slot();
+    bool* ad = &attr[aurppo_device_slot()][num_layers - 1];
     switch (num_layers) {
-        case 1:
-            rc = allow_lds(k_mlpw_act<1>, &attr[dslot][0]);
-            if (rc != AURPPO_OK) return rc;
-            hipLaunchKernelGGL(k_mlpw_act<1>, dim3(grid), dim3(kThreads), wide_lds_bytes(), s, a);
-            break;
-        case 2:
-            rc = allow_lds(k_mlpw_act<2>, &attr[dslot][1]);
-            if (rc != AURPPO_OK) return rc;
-            hipLaunchKernelGGL(k_mlpw_act<2>, dim3(grid), dim3(kThreads), wide_lds_bytes(), s, a);
-            break;
-        default:
-            rc = allow_lds(k_mlpw_act<3>, &attr[dslot][2]);
-            if (rc != AURPPO_OK) return rc;
-            hipLaunchKernelGGL(k_mlpw_act<3>, dim3(grid), dim3(kThreads), wide_lds_bytes(), s, a);
-            break;
+        case 1: rc = launch_wide(k_mlpw_act<1>, ad, grid, 1, s, a); break;
+        case 2: rc = launch_wide(k_mlpw_act<2>, ad, grid, 1, s, a); break;
+        default: rc = launch_wide(k_mlpw_act<3>, ad, grid, 1, s, a); break;
     }
+    if (rc != AURPPO_OK) return rc;
     AURPPO_LAUNCH_CHECK("k_mlpw_act");
     return AURPPO_OK;
 }
