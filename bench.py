@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--num-steps", type=int, default=128)
     ap.add_argument("--obs-dim", type=int, default=64)
     ap.add_argument("--act-dim", type=int, default=6)
+    ap.add_argument("--hidden-dim", type=int, default=64, help="-d of src/run_ppo.py:33 (default = the BASELINE workload; other "
+                    "shapes run K7w and are not the headline number)")
+    ap.add_argument("--num-layers", type=int, default=2, help="-nl of src/run_ppo.py:37")
     ap.add_argument("--epochs", type=int, default=4)
     ap.add_argument("--minibatches", type=int, default=4)
     ap.add_argument("--cpu-baseline-updates", type=int, default=3, help="timed CPU-oracle updates, median reported (0 = skip)")
@@ -85,8 +88,8 @@ def hyper(args, world):
                 total_timesteps=args.num_steps * args.envs_per_gpu * world, anneal_lr=False, gae_lambda=0.95,
                 num_update_epochs=args.epochs, num_envs=args.envs_per_gpu * world, num_minibatches=args.minibatches,
                 entropy_coeff=0.0, value_coeff=0.5, clip_coeff=0.2, clip_vloss=True, max_grad_norm=0.5,
-                target_kl=None, norm_adv=True, capture_video=False, hidden_dim=64, continuous=True,
-                learning_rate=3e-4, exp_name="bench", num_layers=2, dropout=0.0, gamma=0.99, track=False,
+                target_kl=None, norm_adv=True, capture_video=False, hidden_dim=args.hidden_dim, continuous=True,
+                learning_rate=3e-4, exp_name="bench", num_layers=args.num_layers, dropout=0.0, gamma=0.99, track=False,
                 log=False, save=False, obs_dim=args.obs_dim, act_dim=args.act_dim)
 
 
@@ -161,7 +164,7 @@ def cpu_baseline(args, data, init_sd, n_updates, gpu_first):
     torch.set_num_threads(cores)
     hp = hyper(args, 1)
     T, N = args.num_steps, args.envs_per_gpu
-    net = O.make_actor_critic(args.obs_dim, (args.act_dim,), 64, 2, True)
+    net = O.make_actor_critic(args.obs_dim, (args.act_dim,), args.hidden_dim, args.num_layers, True)
     net.load_state_dict(init_sd)
     opt = torch.optim.Adam(net.parameters(), lr=hp["learning_rate"], eps=1e-5)
     buf = {k: data[k] for k in ("states", "actions", "log_probs", "rewards", "terminals", "values")}
@@ -396,7 +399,9 @@ def main():
         ms = float(np.mean([b.elapsed_time(e) for b, e in mlp_events]))
         flops = H.mlp_step_flops(agent._mlp, M)
         ach = flops / (ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": ("k_mlp_step" if os.environ.get("AURPPO_MLP_VARIANT") == "1" else "k_mlp_step2") + " (K7: gather + actor/critic forward + PPO loss + backward)",
+        kname = ("k_mlpw_step (K7w" if agent._mlp.get("wide") else
+                 ("k_mlp_step" if os.environ.get("AURPPO_MLP_VARIANT") == "1" else "k_mlp_step2") + " (K7")
+        roofline = {"bound": "mfma", "kernel": kname + ": gather + actor/critic forward + PPO loss + backward)",
                     "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": pmc("mlp_pmc.json"),
                     "flops_per_launch": flops, "avg_launch_us": round(ms * 1e3, 2), "launches_timed": len(mlp_events),
@@ -426,12 +431,13 @@ def main():
            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"synthetic continuous obs_dim={Dm} act_dim={A}, num_envs={N}/GPU x {world} GPU, "
-                                  f"T={T}, E={args.epochs}, {args.minibatches} minibatches/epoch (M={M}), 2x64 tanh "
-                                  "MLP actor+critic, Adam, random-init weights",
+                                  f"T={T}, E={args.epochs}, {args.minibatches} minibatches/epoch (M={M}), "
+                                  f"{args.num_layers}x{args.hidden_dim} tanh MLP actor+critic, Adam, random-init weights",
                       "global_num_envs": N * world, "num_steps": T,
                       "parallelism": f"env-shard dp{world}" + (" (one rank through the RCCL launch path)" if args.force_dp else ""),
                       "update_launch": launch,
-                      "minibatch_step": "K7 fused MLP step" if agent._mlp is not None else "K3 + torch nets + K5"},
+                      "minibatch_step": ("K3 + torch nets + K5" if agent._mlp is None else
+                                         "K7w fused MLP step + K6b" if agent._mlp.get("wide") else "K7 fused MLP step")},
            "roofline": roofline}
     parity = None
     if world == 1 and args.cpu_baseline_updates > 0:
