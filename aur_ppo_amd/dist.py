@@ -54,12 +54,14 @@ def shard_envs(num_envs, rank_, world):
     return rank_ * per, (rank_ + 1) * per
 
 
-def allreduce_mean_(flat, world=None):
-    """In-place mean over ranks of one flat tensor (the gradient bucket)."""
+def allreduce_mean_(flat, world=None, force=False):
+    """In-place mean over ranks of one flat tensor (the gradient bucket).  ``force``: issue the collective even in a
+    process group of one (rehearsal of the launch path, as ``allreduce_sum_``)."""
     w = world_size() if world is None else world
-    if w > 1:
+    if w > 1 or (force and dist.is_available() and dist.is_initialized()):
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        flat.mul_(1.0 / w)
+        if w > 1:
+            flat.mul_(1.0 / w)
     return flat
 
 

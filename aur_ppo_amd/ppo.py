@@ -426,7 +426,7 @@ class ppo(FlatAdamMixin):
                     ops.mlp_ppo_step(b_obs, k7_act, k7_rec, mb_inds, self.bucket.flat_param, self._mlp,
                                      self.bucket.flat_grad, self.clip_coeff, self.entropy_coeff, self.value_coeff,
                                      self.norm_adv, vmode, self._scalars[step])
-                    D.allreduce_mean_(self.bucket.flat_grad, self.world)
+                    D.allreduce_mean_(self.bucket.flat_grad, self.world, force=self._dp)
                     self._clip_and_step(self._norms[step:step + 1])
                     step += 1
                     continue

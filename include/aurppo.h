@@ -157,8 +157,8 @@ int aurppo_loss_fwd_bwd_packed_f32(const float* newlogp, const float* newv, cons
  * bucket, layout_h 13 float offsets into it {w1,b1,w2,b2,w3,b3} for the actor, the same for the
  * critic, then actor_logstd (ignored for the Categorical head; nn.Linear layout: weight[out][in]).  `grads` (n_params floats) is
  * OVERWRITTEN with d loss / d params in the same layout; out_scalars as aurppo_loss_fwd_bwd_f32.
- * Built for hidden = 64, D <= 64, A <= 16; other shapes return AURPPO_ESHAPE (callers then use
- * the per-op path).  workspace: aurppo_mlp_workspace_bytes(n_params) bytes, 16-byte aligned.      */
+ * Built for hidden = 64, two layers, D <= 64, A <= 16; other shapes return AURPPO_ESHAPE (callers then use
+ * aurppo_mlp_wide_ppo_step_f32 below, or the per-op path beyond its limits).  workspace: aurppo_mlp_workspace_bytes(n_params) bytes, 16-byte aligned.      */
 size_t aurppo_mlp_workspace_bytes(int n_params);
 int aurppo_mlp_ppo_step_f32(const float* obs, const float* actions, const float* rec,
                             const int32_t* idx, int M, int D, int A, int continuous, int hidden,

@@ -116,7 +116,7 @@ def test_two_ranks_on_the_hip_path(tmp_path):
 
 
 # ---------------------------------------------------------------------------------- RCCL: the captured collective
-def _rccl_worker(rank, world, port, out_dir, force_dp, use_graph):
+def _rccl_worker(rank, world, port, out_dir, force_dp, use_graph, over=None):
     """One process per device over backend "nccl" (= RCCL).  world == 1 + force_dp: the multi-GPU launch path (K7 grad ->
     all-reduce -> apply) through a communicator of one -- what a one-GPU box can rehearse of the captured collective."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
@@ -127,7 +127,7 @@ def _rccl_worker(rank, world, port, out_dir, force_dp, use_graph):
     from aur_ppo_amd.ppo import ppo
     torch.manual_seed(50 + rank)
     agent = ppo(_params(64, device=torch.device("cuda", rank), force_dp=force_dp, hip_graph=use_graph,
-                        total_timesteps=16 * 64 * 4))
+                        total_timesteps=16 * 64 * 4, **(over or {})))
     per = 64 // world
     assert agent._dp and agent.num_envs == per and agent.use_graph == use_graph
     p0 = agent.bucket.flat_param.clone().cpu()
@@ -154,6 +154,27 @@ def test_one_rank_rccl_update_is_captured_as_hipgraph(tmp_path):
     # the plain single-process trainer (chained K7 -> reduce -> clip+Adam) from the same start
     from aur_ppo_amd.ppo import ppo
     a = ppo(_params(64, total_timesteps=16 * 64 * 4, hip_graph=False))
+    with torch.no_grad():
+        a.bucket.flat_param.copy_(g["p0"].cuda())
+    sc = _run(a, _rollout(16, 64), 0, 64, updates=4)
+    torch.testing.assert_close(g["sc"], sc, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(g["p1"], a.bucket.flat_param.cpu(), rtol=1e-5, atol=1e-7)
+
+
+def test_one_rank_rccl_update_with_a_wide_policy_is_captured(tmp_path):
+    """-d 128 -nl 3 on the W > 1 launch path: 16 x {K7w step, RCCL all-reduce, K6b} in one hipGraph; ends where the eager
+    run and the plain single-process trainer end."""
+    over = dict(hidden_dim=128, num_layers=3)
+    for use_graph in (True, False):
+        mp.start_processes(_rccl_worker, args=(1, _free_port(), str(tmp_path), True, use_graph, over), nprocs=1, join=True,
+                           start_method="spawn")
+    g, e = torch.load(tmp_path / "r0_1.pt"), torch.load(tmp_path / "r0_0.pt")
+    assert g["captured"], f"the update with the collective inside was not captured: {g['fallback']}"
+    torch.testing.assert_close(g["sc"], e["sc"], rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(g["p1"], e["p1"], rtol=1e-6, atol=1e-8)
+    from aur_ppo_amd.ppo import ppo
+    a = ppo(_params(64, total_timesteps=16 * 64 * 4, hip_graph=False, **over))
+    assert a._mlp["wide"]
     with torch.no_grad():
         a.bucket.flat_param.copy_(g["p0"].cuda())
     sc = _run(a, _rollout(16, 64), 0, 64, updates=4)
