@@ -2,12 +2,12 @@
 for the MLP shapes src/run_ppo.py's -d / -nl can ask for.  Prints one JSON object; run on the GPU box:
     python tools/bench_wide.py > gpurun_out/wide_bench.json"""
 import json
+import os
 import sys
-import time
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from aur_ppo_amd import hip_ops as H                       # noqa: E402
 from aur_ppo_amd.actor_critic import actor_critic         # noqa: E402
 from aur_ppo_amd.flat import FlatBucket                   # noqa: E402

@@ -5,6 +5,8 @@
 #   bench_nofused_*.json/csv            bench.py --no-fused-mlp (per-op path: K1, K3, K4+K5, K6b stand-alone durations)
 #   bench_forcedp_*.json/csv            bench.py --force-dp (the W > 1 launch path captured around a one-rank RCCL all-reduce)
 #   mlp_pmc.json                        separate --pmc passes for the K7 kernel's HBM traffic
+#   bench_wide_{3x128,3x64,2x128}*.json/csv   bench.py --hidden-dim/--num-layers (K7w / K8w), plain and under rocprofv3
+#   wide_bench.json                     tools/bench_wide.py: K7w / K8w against the per-op path over the -d / -nl shapes
 # Each step runs under its own timeout; a step that times out stops the script (no GPU step after a hang).
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/prof_final
@@ -28,6 +30,14 @@ prof() {  # prof <tag> <bench args...>
 prof bench
 prof bench_nofused --no-fused-mlp
 prof bench_forcedp --force-dp
+prof bench_wide_3x128 --hidden-dim 128 --num-layers 3 --steps 30
+prof bench_wide_3x64 --hidden-dim 64 --num-layers 3 --steps 30
+prof bench_wide_2x128 --hidden-dim 128 --num-layers 2 --steps 30
+for shape in "128 3" "64 3" "128 2"; do
+  set -- $shape
+  run 600 python3 $R/bench.py --hidden-dim $1 --num-layers $2 --steps 30 --cpu-baseline-updates 1 > $O/bench_wide_$2x$1.json 2> $O/bench_wide_$2x$1.err
+done
+run 600 python3 $R/tools/bench_wide.py > $O/wide_bench.json 2> $O/wide_bench.err
 run 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 2 --warmup 2 --no-probe --cpu-baseline-updates 0 > /dev/null 2>&1
 run 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 2 --warmup 2 --no-probe --cpu-baseline-updates 0 > /dev/null 2>&1
 cd $R
