@@ -130,11 +130,20 @@ __device__ __forceinline__ void mma_breg(f32x16& acc, FA a_at, const float (&b)[
 
 // One output block of a layer: acc = sum over nkb in-blocks of In[:, kb] * Wop[block (hi, kb)], the weight blocks
 // streamed one ahead.  In: [R][LDW] in LDS.
+// LOAD_FIRST = false: `early` already holds (or is loading) the layer's first block -- the caller issued that load a phase
+// early, behind work that does not need it, so its L2 latency is not on the chain (EARLY below; not with three 128-wide
+// layers, whose accumulators leave no registers to hold a block across a phase).
+template <bool LOAD_FIRST>
 __device__ __forceinline__ f32x16 stream_layer(const float* In, const float* wop, int net, int l, int dir, int hi, int nkb,
-                                               int lane) {
+                                               int lane, float (&early)[16]) {
     f32x16 acc = zero16();
     float bq[2][16];
-    load_b(bq[0], op_block(wop, net, l, dir, hi, 0, lane));
+    if (LOAD_FIRST) {
+        load_b(bq[0], op_block(wop, net, l, dir, hi, 0, lane));
+    } else {
+#pragma unroll
+        for (int m = 0; m < 16; ++m) bq[0][m] = early[m];
+    }
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
         if (kb < nkb) {
@@ -214,14 +223,16 @@ __device__ __forceinline__ void stage_small(const WideArgs& a, const WideLds& s,
 }
 
 // forward pass of one net over the tile in sX: H_1 .. H_NL, then the head into sOut (+ bias)
-template <int NL>
-__device__ __forceinline__ void forward_tile(const WideArgs& a, const WideLds& s, int net, int cb, int HB, int DB) {
+template <int NL, bool EARLY>
+__device__ __forceinline__ void forward_tile(const WideArgs& a, const WideLds& s, int net, int cb, int HB, int DB,
+                                             float (&early)[16]) {
     const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
         if (cb < HB) {
             const float* In = l == 0 ? s.sX : s.sH[l - 1];
-            const f32x16 acc = stream_layer(In, a.wop, net, l, 0, cb, l == 0 ? DB : HB, lane);
+            const f32x16 acc = stream_layer<!EARLY>(In, a.wop, net, l, 0, cb, l == 0 ? DB : HB, lane, early);
+            if (EARLY && l + 1 < NL) load_b(early, op_block(a.wop, net, l + 1, 0, cb, 0, lane));   // behind the epilogue and the barrier
             const int col = cb * 32 + (lane & 31);
             const float bias = s.sB[l * HPW + col];
             float* Hl = s.sH[l];
@@ -264,6 +275,7 @@ __global__ __launch_bounds__(256) void k_mlpw_step(const WideArgs a) {
     const int HB = (Hd + 31) >> 5, DB = (D + 31) >> 5;
     const int AW = a.continuous ? A : 1;
     const int out_dim = net == 0 ? A : 1;
+    constexpr bool EARLY = !(NL == 3 && !DUAL);
     constexpr int CHW = NL == 3 ? 4 : 8;   // operand read-ahead of the LDS-fed chains: three layers of accumulators leave fewer registers
 
     if (DUAL) {
@@ -349,6 +361,8 @@ __global__ __launch_bounds__(256) void k_mlpw_step(const WideArgs a) {
     int it = 0;
     for (int tile = pair; tile < n_tiles; tile += n_pairs, ++it) {
         // ---- land the prefetched tile, start fetching the next one
+        float early[16];
+        if (EARLY && cb < HB) load_b(early, op_block(a.wop, net, 0, 0, cb, 0, lane));   // layer 1's first weight block, behind the landing
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
             const int c = x_c0 + 8 * u;
@@ -372,7 +386,7 @@ __global__ __launch_bounds__(256) void k_mlpw_step(const WideArgs a) {
         if (NL < 3) prefetch(s.sIdx + ((it + 1) & 1) * R);
         if (tid < R) n_idx = load_idx(tile + 3 * n_pairs);
 
-        forward_tile<NL>(a, s, net, cb, HB, DB);
+        forward_tile<NL, EARLY>(a, s, net, cb, HB, DB, early);
 
         // ---- loss lanes (one per row): this net's half of the PPO terms; head outputs become their gradients
         if (lrow < R) {
@@ -463,12 +477,13 @@ __global__ __launch_bounds__(256) void k_mlpw_step(const WideArgs a) {
             if (cb < HB) {
                 const float* dZ = s.sH[l];
                 float* Hp = s.sH[l - 1];
+                if (EARLY) load_b(early, op_block(a.wop, net, l, 1, cb, 0, lane));   // dH's first weight block, behind the dW chains
 #pragma unroll
                 for (int ob = 0; ob < OBN; ++ob)
                     if (ob < HB)
                         mma32<R, CHW>(gW[l][ob], [&](int i, int k) { return dZ[k * LDW + ob * 32 + i]; },
                                       [&](int k, int j) { return Hp[k * LDW + cb * 32 + j]; }, lane);
-                const f32x16 acc = stream_layer(dZ, a.wop, net, l, 1, cb, HB, lane);
+                const f32x16 acc = stream_layer<!EARLY>(dZ, a.wop, net, l, 1, cb, HB, lane, early);
                 const int col = cb * 32 + (lane & 31);
                 float colsum = 0.0f;
 #pragma unroll
@@ -574,7 +589,9 @@ __global__ __launch_bounds__(256) void k_mlpw_act(const WideArgs a) {
         }
     }
     __syncthreads();
-    forward_tile<NL>(a, s, net, tid >> 6, HB, DB);
+    float early[16];
+    if ((tid >> 6) < HB) load_b(early, op_block(a.wop, net, 0, 0, tid >> 6, 0, tid & 63));
+    forward_tile<NL, true>(a, s, net, tid >> 6, HB, DB, early);
     if (tid >= R || row0 + tid >= a.N) return;
     const int n = row0 + tid;
     const float* mu = s.sOut + tid * LDO;
