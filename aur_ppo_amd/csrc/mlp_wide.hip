@@ -275,6 +275,7 @@ __global__ __launch_bounds__(256) void k_mlpw_step(const WideArgs a) {
     const int HB = (Hd + 31) >> 5, DB = (D + 31) >> 5;
     const int AW = a.continuous ? A : 1;
     const int out_dim = net == 0 ? A : 1;
+    const bool own_out = (NL < 3 || DUAL) && DB < HB;   // (not with three 128-wide layers: no registers for a second code path)
     constexpr bool EARLY = !(NL == 3 && !DUAL);
     constexpr int CHW = NL == 3 ? 4 : 8;   // operand read-ahead of the LDS-fed chains: three layers of accumulators leave fewer registers
 
@@ -499,8 +500,19 @@ __global__ __launch_bounds__(256) void k_mlpw_step(const WideArgs a) {
             }
             __syncthreads();
         }
-        // ---- dW_1 (in-block w of the state)
-        if (cb < DB) {
+        // ---- dW_1: a wave owns the state's in-block cb and walks the out-blocks, as for the other layers -- unless the
+        // state is narrower than the layer (DB < HB), where owning OUT-block cb and walking the in-blocks keeps every
+        // wave busy (gW[0][k] is then block (cb, k) instead of (k, cb))
+        if (own_out) {
+            if (cb < HB) {
+                const float* dZ = s.sH[0];
+#pragma unroll
+                for (int ib = 0; ib < OBN; ++ib)
+                    if (ib < DB)
+                        mma32<R, CHW>(gW[0][ib], [&](int i, int k) { return dZ[k * LDW + cb * 32 + i]; },
+                                      [&](int k, int j) { return s.sX[k * LDW + ib * 32 + j]; }, lane);
+            }
+        } else if (cb < DB) {
             const float* dZ = s.sH[0];
 #pragma unroll
             for (int ob = 0; ob < OBN; ++ob)
@@ -521,7 +533,16 @@ __global__ __launch_bounds__(256) void k_mlpw_step(const WideArgs a) {
             const int in_dim = l == 0 ? D : Hd;
 #pragma unroll
             for (int ob = 0; ob < OBN; ++ob) {
-                if (ob < HB && col < in_dim) {
+                if (l == 0 && own_out) {       // gW[0][ob] = block (out cb, in ob)
+                    const int c0 = ob * 32 + (lane & 31);
+                    if (ob < DB && cb < HB && c0 < D) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const int o = cb * 32 + acc_row(e, lane);
+                            if (o < Hd) slab[a.L.w[net][0] + o * D + c0] = gW[0][ob][e];
+                        }
+                    }
+                } else if (ob < HB && col < in_dim) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int o = ob * 32 + acc_row(e, lane);
