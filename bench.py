@@ -403,7 +403,8 @@ def main():
                  ("k_mlp_step" if os.environ.get("AURPPO_MLP_VARIANT") == "1" else "k_mlp_step2") + " (K7")
         roofline = {"bound": "mfma", "kernel": kname + ": gather + actor/critic forward + PPO loss + backward)",
                     "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": pmc("mlp_pmc.json"),
+                    "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
+                    "traffic": None if agent._mlp.get("wide") else pmc("mlp_pmc.json"),   # counters were collected for K7 only
                     "flops_per_launch": flops, "avg_launch_us": round(ms * 1e3, 2), "launches_timed": len(mlp_events),
                     "algorithmic_hbm_bytes_per_launch": M * (4 * (Dm + A + 4) + 4),
                     "how": "hipEvent pair recorded inside the library around the K7 kernel, one extra stand-alone "
