@@ -362,13 +362,15 @@ def main():
     env_steps = world * N * T * args.steps
     M = agent.minibatch_size
 
-    def pmc(name):
-        """PMC bytes per launch, collected (separate --pmc passes) on the default workload only."""
+    def pmc(name, key=None):
+        """PMC bytes per launch, collected (separate --pmc passes) on the default workload only (``key``: the net shape of
+        a K7w run, for which only some shapes were collected)."""
         if (M, Dm, A) != (131072, 64, 6):
             return None
         path = os.path.join(ROOT, "profiles", name)
         try:
-            return json.load(open(path)).get("hbm_bytes_per_launch")
+            d = json.load(open(path))
+            return (d[key] if key else d).get("hbm_bytes_per_launch")
         except Exception:
             return None
 
@@ -404,7 +406,8 @@ def main():
         roofline = {"bound": "mfma", "kernel": kname + ": gather + actor/critic forward + PPO loss + backward)",
                     "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
-                    "traffic": None if agent._mlp.get("wide") else pmc("mlp_pmc.json"),   # counters were collected for K7 only
+                    "traffic": (pmc("mlp_wide_pmc.json", f"{args.num_layers}x{args.hidden_dim}") if agent._mlp.get("wide")
+                                else pmc("mlp_pmc.json")),
                     "flops_per_launch": flops, "avg_launch_us": round(ms * 1e3, 2), "launches_timed": len(mlp_events),
                     "algorithmic_hbm_bytes_per_launch": M * (4 * (Dm + A + 4) + 4),
                     "how": "hipEvent pair recorded inside the library around the K7 kernel, one extra stand-alone "
