@@ -654,6 +654,7 @@ constexpr size_t act_lds_bytes() {
 constexpr int kRedGroups = 16;
 // sq_part != nullptr (chained minibatch step): also the clip's partial sums of squares, one per workgroup; step_dev != nullptr: the Adam
 // step count is advanced and the tile counter of the next K7 launch is cleared.
+template <int HALVES>   // 16 slab rows per thread and half: 256 slabs (K7, K7w) or 512 (K7w with two workgroups per CU)
 __global__ __launch_bounds__(1024) void k_mlp_reduce(const float* __restrict__ slabs, const double* __restrict__ loss_part,
                                                      int n_slabs, int n_params, PpoHyper h, float* __restrict__ grads,
                                                      float* __restrict__ out_scalars, double* __restrict__ sq_part,
@@ -666,16 +667,20 @@ __global__ __launch_bounds__(1024) void k_mlp_reduce(const float* __restrict__ s
         // n_slabs <= kMaxGrid = 16 groups x 16: a thread's rows are all fetched before the first add (one memory round
         // trip, not four); rows past n_slabs read as zero; the order of the adds is fixed
         static_assert(kMaxGrid <= 16 * kRedGroups, "k_mlp_reduce: 16 rows per thread cover the grid");
-        float x[16];
+        float x[16 * HALVES];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
+        for (int j = 0; j < 16 * HALVES; ++j) {
             const int b = grp + j * kRedGroups;
             x[j] = b < n_slabs ? slabs[(size_t)b * n_params + p] : 0.0f;
         }
-        float a4[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) a4[k] = ((x[k] + x[k + 4]) + x[k + 8]) + x[k + 12];
-        acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+        for (int h = 0; h < HALVES; ++h) {
+            float a4[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a4[k] = ((x[16 * h + k] + x[16 * h + k + 4]) + x[16 * h + k + 8]) + x[16 * h + k + 12];
+            const float ah = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+            acc = h == 0 ? ah : acc + ah;
+        }
     }
     s_part[grp][pi] = acc;
     __syncthreads();
@@ -975,7 +980,7 @@ static int mlp_step_impl(const float* obs, const float* actions, const float* re
     }
     if (ev_end) AURPPO_HIP_TRY(hipEventRecord((hipEvent_t)ev_end, s));
     const int n_red = (n_params + 63) / 64;
-    hipLaunchKernelGGL(k_mlp_reduce, dim3(n_red), dim3(1024), 0, s, a.slabs, a.loss_part, grid, n_params, a.h, grads,
+    hipLaunchKernelGGL(k_mlp_reduce<1>, dim3(n_red), dim3(1024), 0, s, a.slabs, a.loss_part, grid, n_params, a.h, grads,
                        out_scalars, (chain && !chain->grad_only) ? sq_part : nullptr, chain ? chain->step_dev : nullptr,
                        a.tile_counter);
     AURPPO_LAUNCH_CHECK("k_mlp_reduce");
@@ -995,9 +1000,13 @@ static int mlp_step_impl(const float* obs, const float* actions, const float* re
 
 int aurppo_mlp::launch_mlp_reduce(const float* slabs, const double* loss_part, int n_slabs, int n_params, const PpoHyper& h,
                                   float* grads, float* out_scalars, hipStream_t s) {
-    AURPPO_REQUIRE(n_slabs >= 1 && n_slabs <= kMaxGrid, AURPPO_ESHAPE, "launch_mlp_reduce: n_slabs=%d", n_slabs);
-    hipLaunchKernelGGL(k_mlp_reduce, dim3((n_params + 63) / 64), dim3(1024), 0, s, slabs, loss_part, n_slabs, n_params, h, grads,
-                       out_scalars, (double*)nullptr, (float*)nullptr, (unsigned*)nullptr);
+    AURPPO_REQUIRE(n_slabs >= 1 && n_slabs <= 2 * kMaxGrid, AURPPO_ESHAPE, "launch_mlp_reduce: n_slabs=%d", n_slabs);
+    if (n_slabs <= kMaxGrid)
+        hipLaunchKernelGGL(k_mlp_reduce<1>, dim3((n_params + 63) / 64), dim3(1024), 0, s, slabs, loss_part, n_slabs, n_params, h,
+                           grads, out_scalars, (double*)nullptr, (float*)nullptr, (unsigned*)nullptr);
+    else
+        hipLaunchKernelGGL(k_mlp_reduce<2>, dim3((n_params + 63) / 64), dim3(1024), 0, s, slabs, loss_part, n_slabs, n_params, h,
+                           grads, out_scalars, (double*)nullptr, (float*)nullptr, (unsigned*)nullptr);
     AURPPO_LAUNCH_CHECK("k_mlp_reduce");
     return AURPPO_OK;
 }

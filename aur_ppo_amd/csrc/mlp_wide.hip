@@ -32,6 +32,7 @@ constexpr int MAXL = 3;             // hidden layers
 constexpr int kOpBlk = 64 * 16;     // floats of one 32x32 block in operand order: [lane][16 k-steps]
 constexpr int kOpLayer = 16 * kOpBlk;                 // 4 x 4 blocks
 constexpr int kOpFloats = 2 * MAXL * 2 * kOpLayer;    // [net][layer][fwd | bwd]
+constexpr int kMaxSlabs = 2 * kMaxGrid;               // k_mlp_reduce folds up to 512
 
 struct WideLayout {   // float offsets into the flat parameter / gradient bucket; layer NL is the head
     int w[2][MAXL + 1], b[2][MAXL + 1];
@@ -133,7 +134,7 @@ __device__ __forceinline__ void mma_breg(f32x16& acc, FA a_at, const float (&b)[
 // LOAD_FIRST = false: `early` already holds (or is loading) the layer's first block -- the caller issued that load a phase
 // early, behind work that does not need it, so its L2 latency is not on the chain (EARLY below; not with three 128-wide
 // layers, whose accumulators leave no registers to hold a block across a phase).
-template <bool LOAD_FIRST>
+template <bool LOAD_FIRST, int LD_>
 __device__ __forceinline__ f32x16 stream_layer(const float* In, const float* wop, int net, int l, int dir, int hi, int nkb,
                                                int lane, float (&early)[16]) {
     f32x16 acc = zero16();
@@ -148,7 +149,7 @@ __device__ __forceinline__ f32x16 stream_layer(const float* In, const float* wop
     for (int kb = 0; kb < 4; ++kb) {
         if (kb < nkb) {
             if (kb + 1 < nkb) load_b(bq[(kb + 1) & 1], op_block(wop, net, l, dir, hi, kb + 1, lane));
-            mma_breg(acc, [&](int i, int k) { return In[i * LDW + kb * 32 + k]; }, bq[kb & 1], lane);
+            mma_breg(acc, [&](int i, int k) { return In[i * LD_ + kb * 32 + k]; }, bq[kb & 1], lane);
         }
     }
     return acc;
@@ -171,19 +172,27 @@ struct WideLds {
 };
 
 // [sX][per-net block x nslots][sAct sDls sLs sIvar sRec sSrc sIdx]: one net per workgroup, or both (nslots = 2) when the
-// layers are at most 64 wide -- see k_mlpw_step
-constexpr int kNetFloats = MAXL * R * LDW + AP * LDW + R * LDO + MAXL * HPW + AP;
+// layers are at most 64 wide -- see k_mlpw_step.  NARROW (that case): row stride 65 and 64 bias slots per layer, so that two
+// such workgroups fit one CU's 160 KB.
+template <bool NARROW> struct Geo {
+    static constexpr int LD = NARROW ? 65 : LDW;      // row stride of an activation matrix (odd either way)
+    static constexpr int HP = NARROW ? 64 : HPW;      // bias slots per layer
+};
+template <bool NARROW, int NL>
+constexpr int net_floats() { return NL * R * Geo<NARROW>::LD + AP * Geo<NARROW>::LD + R * LDO + MAXL * Geo<NARROW>::HP + AP; }
 constexpr int kTailFloats = 2 * R * LDO + 2 * AP;
+template <bool NARROW, int NL>
 __device__ __forceinline__ WideLds carve(float* lds, int slot, int nslots) {
+    constexpr int LD_ = Geo<NARROW>::LD;
     WideLds s;
     s.sX = lds;
-    float* nb = lds + R * LDW + slot * kNetFloats;
-    for (int l = 0; l < MAXL; ++l) s.sH[l] = nb + l * R * LDW;
-    s.sW3 = nb + MAXL * R * LDW;
-    s.sOut = s.sW3 + AP * LDW;
+    float* nb = lds + R * LD_ + slot * net_floats<NARROW, NL>();
+    for (int l = 0; l < MAXL; ++l) s.sH[l] = nb + (l < NL ? l : 0) * R * LD_;
+    s.sW3 = nb + NL * R * LD_;
+    s.sOut = s.sW3 + AP * LD_;
     s.sB = s.sOut + R * LDO;
-    s.sB3 = s.sB + MAXL * HPW;
-    float* tail = lds + R * LDW + nslots * kNetFloats;
+    s.sB3 = s.sB + MAXL * Geo<NARROW>::HP;
+    float* tail = lds + R * LD_ + nslots * net_floats<NARROW, NL>();
     s.sAct = tail;
     s.sDls = s.sAct + R * LDO;
     s.sLs = s.sDls + R * LDO;
@@ -193,23 +202,27 @@ __device__ __forceinline__ WideLds carve(float* lds, int slot, int nslots) {
     s.sIdx = s.sSrc + R;
     return s;
 }
-static_assert((R * LDW) % 4 == 0 && kNetFloats % 4 == 0 && kTailFloats % 4 == 0, "sRec must be 16-B aligned");
+static_assert((R * LDW) % 4 == 0 && (R * 65) % 4 == 0 && net_floats<false, 1>() % 4 == 0 && net_floats<false, 2>() % 4 == 0 &&
+              net_floats<false, 3>() % 4 == 0 && net_floats<true, 1>() % 4 == 0 && net_floats<true, 2>() % 4 == 0 &&
+              net_floats<true, 3>() % 4 == 0 && kTailFloats % 4 == 0, "sRec must be 16-B aligned");
+template <bool NARROW, int NL>
 constexpr size_t wide_lds_bytes(int nslots) {
-    return sizeof(float) * (size_t)(R * LDW + nslots * kNetFloats + kTailFloats + 4 * R + R + 2 * R);
+    return sizeof(float) * (size_t)(R * Geo<NARROW>::LD + nslots * net_floats<NARROW, NL>() + kTailFloats + 4 * R + R + 2 * R);
 }
-static_assert(wide_lds_bytes(2) <= 160 * 1024, "both nets of a <= 64-wide policy must fit one CU's LDS");
+static_assert(2 * (wide_lds_bytes<true, 3>(2) + 1024) <= 160 * 1024, "two both-net workgroups of a <= 64-wide policy must fit one CU's LDS");
 
 // weights that stay in LDS: the head, every bias, log-std
-template <int NL>
+template <int NL, bool NARROW>
 __device__ __forceinline__ void stage_small(const WideArgs& a, const WideLds& s, int net, bool act_mode) {
+    constexpr int LD_ = Geo<NARROW>::LD, HP_ = Geo<NARROW>::HP;
     const int tid = threadIdx.x, Hd = a.Hd, out_dim = net == 0 ? a.A : 1;
-    for (int e = tid; e < R * LDW; e += kThreads) s.sX[e] = 0.0f;
-    for (int e = tid; e < AP * LDW; e += kThreads) {
-        const int o = e / LDW, i = e - o * LDW;
+    for (int e = tid; e < R * LD_; e += kThreads) s.sX[e] = 0.0f;
+    for (int e = tid; e < AP * LD_; e += kThreads) {
+        const int o = e / LD_, i = e - o * LD_;
         s.sW3[e] = (o < out_dim && i < Hd) ? a.params[a.L.w[net][NL] + o * Hd + i] : 0.0f;
     }
-    for (int e = tid; e < NL * HPW; e += kThreads) {
-        const int l = e / HPW, c = e - l * HPW;
+    for (int e = tid; e < NL * HP_; e += kThreads) {
+        const int l = e / HP_, c = e - l * HP_;
         s.sB[e] = c < Hd ? a.params[a.L.b[net][l] + c] : 0.0f;
     }
     if (tid < AP) {
@@ -223,32 +236,33 @@ __device__ __forceinline__ void stage_small(const WideArgs& a, const WideLds& s,
 }
 
 // forward pass of one net over the tile in sX: H_1 .. H_NL, then the head into sOut (+ bias)
-template <int NL, bool EARLY>
+template <int NL, bool EARLY, bool NARROW>
 __device__ __forceinline__ void forward_tile(const WideArgs& a, const WideLds& s, int net, int cb, int HB, int DB,
                                              float (&early)[16]) {
+    constexpr int LD_ = Geo<NARROW>::LD, HP_ = Geo<NARROW>::HP;
     const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
         if (cb < HB) {
             const float* In = l == 0 ? s.sX : s.sH[l - 1];
-            const f32x16 acc = stream_layer<!EARLY>(In, a.wop, net, l, 0, cb, l == 0 ? DB : HB, lane, early);
+            const f32x16 acc = stream_layer<!EARLY, LD_>(In, a.wop, net, l, 0, cb, l == 0 ? DB : HB, lane, early);
             if (EARLY && l + 1 < NL) load_b(early, op_block(a.wop, net, l + 1, 0, cb, 0, lane));   // behind the epilogue and the barrier
             const int col = cb * 32 + (lane & 31);
-            const float bias = s.sB[l * HPW + col];
+            const float bias = s.sB[l * HP_ + col];
             float* Hl = s.sH[l];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) Hl[acc_row(e, lane) * LDW + col] = tanh_fast(acc[e] + bias);
+            for (int e = 0; e < 16; ++e) Hl[acc_row(e, lane) * LD_ + col] = tanh_fast(acc[e] + bias);
         }
         __syncthreads();
     }
     if (cb < 2) {   // head: 16 rows per wave as one 16x16 tile, K = HB blocks of 32
-        const float* Hin = s.sH[NL - 1] + cb * 16 * LDW;
+        const float* Hin = s.sH[NL - 1] + cb * 16 * LD_;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb)
             if (kb < HB)
-                acc += mma16<32>([&](int i, int k) { return Hin[i * LDW + kb * 32 + k]; },
-                                 [&](int k, int j) { return s.sW3[j * LDW + kb * 32 + k]; });
+                acc += mma16<32>([&](int i, int k) { return Hin[i * LD_ + kb * 32 + k]; },
+                                 [&](int k, int j) { return s.sW3[j * LD_ + kb * 32 + k]; });
         const int col = lane & 15;
         const float bias = s.sB3[col];
 #pragma unroll
@@ -261,29 +275,31 @@ __device__ __forceinline__ void forward_tile(const WideArgs& a, const WideLds& s
 // DUAL = true (layers and state at most 64 wide, i.e. two column blocks): a workgroup is BOTH nets of its tiles -- waves
 // 0,1 the actor's two column blocks, waves 2,3 the critic's -- so no wave idles and a tile's rows are fetched once.
 template <int NL, bool DUAL>
-__global__ __launch_bounds__(256) void k_mlpw_step(const WideArgs a) {
+__global__ __launch_bounds__(256, DUAL ? 2 : 1) void k_mlpw_step(const WideArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ double s_red[2][kThreads / kWave];
     __shared__ float s_mean, s_std;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int net = DUAL ? (w >> 1) : (int)(blockIdx.x & 1), cb = DUAL ? (w & 1) : w;
     const int pair = DUAL ? (int)blockIdx.x : (int)(blockIdx.x >> 1), n_pairs = DUAL ? (int)gridDim.x : (int)(gridDim.x >> 1);
-    const WideLds s = carve(lds, DUAL ? net : 0, DUAL ? 2 : 1);
+    constexpr int LD_ = Geo<DUAL>::LD;
+    constexpr int XS = DUAL ? 8 : 16;    // staging slots per thread: columns (tid & 7) + 8u cover 64 or 128 state floats
+    const WideLds s = carve<DUAL, NL>(lds, DUAL ? net : 0, DUAL ? 2 : 1);
     const int hw = DUAL ? 1 : 3;          // the actor wave that also forms the head-side column sums
     const int lrow = DUAL ? (tid & 127) : tid;   // loss lanes: the first 32 lanes of each net's first wave
     const int D = a.D, A = a.A, Hd = a.Hd;
     const int HB = (Hd + 31) >> 5, DB = (D + 31) >> 5;
     const int AW = a.continuous ? A : 1;
     const int out_dim = net == 0 ? A : 1;
-    const bool own_out = (NL < 3 || DUAL) && DB < HB;   // (not with three 128-wide layers: no registers for a second code path)
-    constexpr bool EARLY = !(NL == 3 && !DUAL);
-    constexpr int CHW = NL == 3 ? 4 : 8;   // operand read-ahead of the LDS-fed chains: three layers of accumulators leave fewer registers
+    const bool own_out = NL < 3 && DB < HB;   // (not with three layers: no registers for a second code path)
+    constexpr bool EARLY = DUAL ? NL == 1 : NL < 3;   // holding a weight block across a phase costs 16 registers
+    constexpr int CHW = (NL == 3 || DUAL) ? 4 : 8;   // operand read-ahead of the LDS-fed chains: three layers of accumulators leave fewer registers
 
     if (DUAL) {
-        stage_small<NL>(a, carve(lds, 0, 2), 0, false);
-        stage_small<NL>(a, carve(lds, 1, 2), 1, false);
+        stage_small<NL, DUAL>(a, carve<DUAL, NL>(lds, 0, 2), 0, false);
+        stage_small<NL, DUAL>(a, carve<DUAL, NL>(lds, 1, 2), 1, false);
     } else {
-        stage_small<NL>(a, s, net, false);
+        stage_small<NL, DUAL>(a, s, net, false);
     }
     {
         double sm = 0.0, q = 0.0;
@@ -323,7 +339,7 @@ __global__ __launch_bounds__(256) void k_mlpw_step(const WideArgs a) {
     const int n_tiles = (a.h.M + R - 1) / R;
     // staging slots: 8 threads per row, columns (tid & 7) + 8u
     const int x_r = tid >> 3, x_c0 = tid & 7;
-    float xr[16], ar[2];
+    float xr[XS], ar[2];
     float4 p_rec = make_float4(0.f, 0.f, 0.f, 0.f);
     int p_src = -1, n_idx = -1;
     auto load_idx = [&](int tile) -> int {
@@ -335,7 +351,7 @@ __global__ __launch_bounds__(256) void k_mlpw_step(const WideArgs a) {
     auto prefetch = [&](const int* sidx) {
         const int src = sidx[x_r];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < XS; ++u) {
             const int c = x_c0 + 8 * u;
             xr[u] = (src >= 0 && c < D) ? a.obs[(size_t)src * D + c] : 0.0f;
         }
@@ -365,9 +381,9 @@ __global__ __launch_bounds__(256) void k_mlpw_step(const WideArgs a) {
         float early[16];
         if (EARLY && cb < HB) load_b(early, op_block(a.wop, net, 0, 0, cb, 0, lane));   // layer 1's first weight block, behind the landing
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < XS; ++u) {
             const int c = x_c0 + 8 * u;
-            if (c < D) s.sX[x_r * LDW + c] = xr[u];
+            if (c < D) s.sX[x_r * LD_ + c] = xr[u];
         }
         if (DUAL || net == 0) {
 #pragma unroll
@@ -387,7 +403,7 @@ __global__ __launch_bounds__(256) void k_mlpw_step(const WideArgs a) {
         if (NL < 3) prefetch(s.sIdx + ((it + 1) & 1) * R);
         if (tid < R) n_idx = load_idx(tile + 3 * n_pairs);
 
-        forward_tile<NL, EARLY>(a, s, net, cb, HB, DB, early);
+        forward_tile<NL, EARLY, DUAL>(a, s, net, cb, HB, DB, early);
 
         // ---- loss lanes (one per row): this net's half of the PPO terms; head outputs become their gradients
         if (lrow < R) {
@@ -455,14 +471,14 @@ __global__ __launch_bounds__(256) void k_mlpw_step(const WideArgs a) {
             float* HL = s.sH[NL - 1];
             f32x16 acc = zero16();
             mma32<AP>(acc, [&](int i, int k) { return s.sOut[i * LDO + k]; },
-                      [&](int k, int j) { return s.sW3[k * LDW + cb * 32 + j]; });
+                      [&](int k, int j) { return s.sW3[k * LD_ + cb * 32 + j]; });
             mma32<R, CHW>(gW3, [&](int i, int k) { return i < AP ? s.sOut[k * LDO + i] : 0.0f; },
-                          [&](int k, int j) { return HL[k * LDW + cb * 32 + j]; }, lane);
+                          [&](int k, int j) { return HL[k * LD_ + cb * 32 + j]; }, lane);
             const int col = cb * 32 + (lane & 31);
             float colsum = 0.0f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                float* hp = HL + acc_row(e, lane) * LDW + col;
+                float* hp = HL + acc_row(e, lane) * LD_ + col;
                 const float h = *hp;
                 const float dz = acc[e] * (1.0f - h * h);
                 colsum += dz;
@@ -482,14 +498,14 @@ __global__ __launch_bounds__(256) void k_mlpw_step(const WideArgs a) {
 #pragma unroll
                 for (int ob = 0; ob < OBN; ++ob)
                     if (ob < HB)
-                        mma32<R, CHW>(gW[l][ob], [&](int i, int k) { return dZ[k * LDW + ob * 32 + i]; },
-                                      [&](int k, int j) { return Hp[k * LDW + cb * 32 + j]; }, lane);
-                const f32x16 acc = stream_layer<!EARLY>(dZ, a.wop, net, l, 1, cb, HB, lane, early);
+                        mma32<R, CHW>(gW[l][ob], [&](int i, int k) { return dZ[k * LD_ + ob * 32 + i]; },
+                                      [&](int k, int j) { return Hp[k * LD_ + cb * 32 + j]; }, lane);
+                const f32x16 acc = stream_layer<!EARLY, LD_>(dZ, a.wop, net, l, 1, cb, HB, lane, early);
                 const int col = cb * 32 + (lane & 31);
                 float colsum = 0.0f;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    float* hp = Hp + acc_row(e, lane) * LDW + col;
+                    float* hp = Hp + acc_row(e, lane) * LD_ + col;
                     const float h = *hp;
                     const float dz = acc[e] * (1.0f - h * h);
                     colsum += dz;
@@ -509,16 +525,16 @@ __global__ __launch_bounds__(256) void k_mlpw_step(const WideArgs a) {
 #pragma unroll
                 for (int ib = 0; ib < OBN; ++ib)
                     if (ib < DB)
-                        mma32<R, CHW>(gW[0][ib], [&](int i, int k) { return dZ[k * LDW + cb * 32 + i]; },
-                                      [&](int k, int j) { return s.sX[k * LDW + ib * 32 + j]; }, lane);
+                        mma32<R, CHW>(gW[0][ib], [&](int i, int k) { return dZ[k * LD_ + cb * 32 + i]; },
+                                      [&](int k, int j) { return s.sX[k * LD_ + ib * 32 + j]; }, lane);
             }
         } else if (cb < DB) {
             const float* dZ = s.sH[0];
 #pragma unroll
             for (int ob = 0; ob < OBN; ++ob)
                 if (ob < HB)
-                    mma32<R, CHW>(gW[0][ob], [&](int i, int k) { return dZ[k * LDW + ob * 32 + i]; },
-                                  [&](int k, int j) { return s.sX[k * LDW + cb * 32 + j]; }, lane);
+                    mma32<R, CHW>(gW[0][ob], [&](int i, int k) { return dZ[k * LD_ + ob * 32 + i]; },
+                                  [&](int k, int j) { return s.sX[k * LD_ + cb * 32 + j]; }, lane);
         }
         if (NL >= 3) prefetch(s.sIdx + ((it + 1) & 1) * R);
         __syncthreads();
@@ -595,11 +611,11 @@ __global__ __launch_bounds__(256) void k_mlpw_step(const WideArgs a) {
 template <int NL>
 __global__ __launch_bounds__(256) void k_mlpw_act(const WideArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const WideLds s = carve(lds, 0, 1);
+    const WideLds s = carve<false, NL>(lds, 0, 1);
     const int tid = threadIdx.x;
     const int net = a.net_base + (int)(blockIdx.x % a.net_count), row0 = (int)(blockIdx.x / a.net_count) * R;
     const int D = a.D, A = a.A, HB = (a.Hd + 31) >> 5, DB = (D + 31) >> 5;
-    stage_small<NL>(a, s, net, true);
+    stage_small<NL, false>(a, s, net, true);
     __syncthreads();
     {
         const int r = tid >> 3, n = row0 + r;
@@ -612,7 +628,7 @@ __global__ __launch_bounds__(256) void k_mlpw_act(const WideArgs a) {
     __syncthreads();
     float early[16];
     if ((tid >> 6) < HB) load_b(early, op_block(a.wop, net, 0, 0, tid >> 6, 0, tid & 63));
-    forward_tile<NL, true>(a, s, net, tid >> 6, HB, DB, early);
+    forward_tile<NL, true, false>(a, s, net, tid >> 6, HB, DB, early);
     if (tid >= R || row0 + tid >= a.N) return;
     const int n = row0 + tid;
     const float* mu = s.sOut + tid * LDO;
@@ -654,16 +670,16 @@ __global__ __launch_bounds__(256) void k_mlpw_act(const WideArgs a) {
 
 struct WideWs {
     double* stats;       // (kStatBlocks, 2)
-    double* loss_part;   // (kMaxGrid, 8)
+    double* loss_part;   // (kMaxSlabs, 8)
     float* wop;          // kOpFloats
-    float* slabs;        // (kMaxGrid, n_params)
+    float* slabs;        // (kMaxSlabs, n_params)
 };
 WideWs wide_ws(void* workspace) {
     WideWs v;
     char* p = reinterpret_cast<char*>(workspace);
     v.stats = reinterpret_cast<double*>(p);
     v.loss_part = v.stats + 2 * kStatBlocks;
-    v.wop = reinterpret_cast<float*>(v.loss_part + 8 * kMaxGrid);
+    v.wop = reinterpret_cast<float*>(v.loss_part + 8 * kMaxSlabs);
     v.slabs = v.wop + kOpFloats;
     return v;
 }
@@ -693,21 +709,22 @@ int check_shape(int D, int A, int continuous, int hidden, int num_layers, const 
 }
 
 template <class K>
-int launch_wide(K kernel, bool* attr_done, int grid, int nslots, hipStream_t s, const WideArgs& a) {
+int launch_wide(K kernel, bool* attr_done, int grid, size_t lds_bytes, hipStream_t s, const WideArgs& a) {
     if (!*attr_done) {
         AURPPO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)wide_lds_bytes(nslots)));
+                                           (int)lds_bytes));
         *attr_done = true;
     }
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kThreads), wide_lds_bytes(nslots), s, a);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kThreads), lds_bytes, s, a);
     return AURPPO_OK;
 }
 
 }  // namespace
 
 extern "C" size_t aurppo_mlp_wide_workspace_bytes(int n_params) {
-    return sizeof(double) * (2 * kStatBlocks + 8 * kMaxGrid) + sizeof(float) * (size_t)kOpFloats +
-           sizeof(float) * (size_t)kMaxGrid * (size_t)n_params + 64;
+    // slabs: two both-net workgroups per CU for the narrow shapes (their n_params is small), one pair per two CUs otherwise
+    return sizeof(double) * (2 * kStatBlocks + 8 * kMaxSlabs) + sizeof(float) * (size_t)kOpFloats +
+           sizeof(float) * (size_t)kMaxSlabs * (size_t)n_params + 64;
 }
 
 extern "C" int aurppo_mlp_wide_ppo_step_f32(const float* obs, const float* actions, const float* rec, const int32_t* idx, int M,
@@ -750,8 +767,9 @@ extern "C" int aurppo_mlp_wide_ppo_step_f32(const float* obs, const float* actio
     const int n_tiles = (M + R - 1) / R;
     // layers and state at most two 32-column blocks wide: one workgroup carries both nets (k_mlpw_step<., true>)
     const bool dual = hidden <= 64 && D <= 64;
-    int pairs = dual ? cus_of[dslot] - 8 : (cus_of[dslot] - 8) / 2;      // 8 CUs left to the side stream's shuffle kernels, as K7
-    if (pairs > (dual ? kMaxGrid : kMaxGrid / 2)) pairs = dual ? kMaxGrid : kMaxGrid / 2;
+    // 8 CUs left to the side stream's shuffle kernels, as K7; a both-net workgroup is built to share its CU with a second one
+    int pairs = dual ? 2 * (cus_of[dslot] - 8) : (cus_of[dslot] - 8) / 2;
+    if (pairs > (dual ? kMaxSlabs : kMaxGrid / 2)) pairs = dual ? kMaxSlabs : kMaxGrid / 2;
     if (pairs > n_tiles) pairs = n_tiles;
     if (pairs < 1) pairs = 1;
     static bool attr[kMaxDevices][2][MAXL] = {};
@@ -759,12 +777,12 @@ extern "C" int aurppo_mlp_wide_ppo_step_f32(const float* obs, const float* actio
     const int grid = dual ? pairs : 2 * pairs;
     bool* ad = &attr[dslot][dual ? 1 : 0][num_layers - 1];
     switch (num_layers * 2 + (dual ? 1 : 0)) {
-        case 2: rc = launch_wide(k_mlpw_step<1, false>, ad, grid, 1, s, a); break;
-        case 3: rc = launch_wide(k_mlpw_step<1, true>, ad, grid, 2, s, a); break;
-        case 4: rc = launch_wide(k_mlpw_step<2, false>, ad, grid, 1, s, a); break;
-        case 5: rc = launch_wide(k_mlpw_step<2, true>, ad, grid, 2, s, a); break;
-        case 6: rc = launch_wide(k_mlpw_step<3, false>, ad, grid, 1, s, a); break;
-        default: rc = launch_wide(k_mlpw_step<3, true>, ad, grid, 2, s, a); break;
+        case 2: rc = launch_wide(k_mlpw_step<1, false>, ad, grid, wide_lds_bytes<false, 1>(1), s, a); break;
+        case 3: rc = launch_wide(k_mlpw_step<1, true>, ad, grid, wide_lds_bytes<true, 1>(2), s, a); break;
+        case 4: rc = launch_wide(k_mlpw_step<2, false>, ad, grid, wide_lds_bytes<false, 2>(1), s, a); break;
+        case 5: rc = launch_wide(k_mlpw_step<2, true>, ad, grid, wide_lds_bytes<true, 2>(2), s, a); break;
+        case 6: rc = launch_wide(k_mlpw_step<3, false>, ad, grid, wide_lds_bytes<false, 3>(1), s, a); break;
+        default: rc = launch_wide(k_mlpw_step<3, true>, ad, grid, wide_lds_bytes<true, 3>(2), s, a); break;
     }
     if (rc != AURPPO_OK) return rc;
     AURPPO_LAUNCH_CHECK("k_mlpw_step");
@@ -799,9 +817,9 @@ extern "C" int aurppo_mlp_wide_act_f32(const float* obs, const float* noise, int
     static bool attr[kMaxDevices][MAXL] = {};
     bool* ad = &attr[aurppo_device_slot()][num_layers - 1];
     switch (num_layers) {
-        case 1: rc = launch_wide(k_mlpw_act<1>, ad, grid, 1, s, a); break;
-        case 2: rc = launch_wide(k_mlpw_act<2>, ad, grid, 1, s, a); break;
-        default: rc = launch_wide(k_mlpw_act<3>, ad, grid, 1, s, a); break;
+        case 1: rc = launch_wide(k_mlpw_act<1>, ad, grid, wide_lds_bytes<false, 1>(1), s, a); break;
+        case 2: rc = launch_wide(k_mlpw_act<2>, ad, grid, wide_lds_bytes<false, 2>(1), s, a); break;
+        default: rc = launch_wide(k_mlpw_act<3>, ad, grid, wide_lds_bytes<false, 3>(1), s, a); break;
     }
     if (rc != AURPPO_OK) return rc;
     AURPPO_LAUNCH_CHECK("k_mlpw_act");
