@@ -50,6 +50,7 @@ struct WideArgs {
     float* slabs;          // (pairs, n_params)
     double* loss_part;     // (pairs, 8)
     const double* stats;   // (n_stat_blocks, 2)
+    unsigned* tile_counter;   // [2]: next tile to hand out, per net (one-net workgroups) or [0] alone (both-net workgroups)
     int n_stat_blocks;
     int D, A, Hd, continuous;
     WideLayout L;
@@ -68,8 +69,9 @@ struct WideArgs {
 __global__ __launch_bounds__(256) void k_mlpw_prep(const float* __restrict__ params, WideLayout L, int NL, int D, int Hd,
                                                    float* __restrict__ wop, const float4* __restrict__ rec, int rec_stride,
                                                    const int32_t* __restrict__ idx, int M, double (*__restrict__ stats)[2],
-                                                   int n_stat_blocks) {
+                                                   int n_stat_blocks, unsigned* __restrict__ tile_counter) {
     __shared__ double sc[2][4];
+    if (tile_counter && blockIdx.x == 0 && threadIdx.x < 2) tile_counter[threadIdx.x] = 0u;
     if ((int)blockIdx.x < n_stat_blocks) {
         double s = 0.0, q = 0.0;
         for (int i = blockIdx.x * 256 + threadIdx.x; i < M; i += n_stat_blocks * 256) {
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(256, DUAL ? 2 : 1) void k_mlpw_step(const WideArgs 
     __shared__ float s_mean, s_std;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int net = DUAL ? (w >> 1) : (int)(blockIdx.x & 1), cb = DUAL ? (w & 1) : w;
-    const int pair = DUAL ? (int)blockIdx.x : (int)(blockIdx.x >> 1), n_pairs = DUAL ? (int)gridDim.x : (int)(gridDim.x >> 1);
+    const int pair = DUAL ? (int)blockIdx.x : (int)(blockIdx.x >> 1);
     constexpr int LD_ = Geo<DUAL>::LD;
     constexpr int XS = DUAL ? 8 : 16;    // staging slots per thread: columns (tid & 7) + 8u cover 64 or 128 state floats
     const WideLds s = carve<DUAL, NL>(lds, DUAL ? net : 0, DUAL ? 2 : 1);
@@ -368,15 +370,28 @@ __global__ __launch_bounds__(256, DUAL ? 2 : 1) void k_mlpw_step(const WideArgs 
             if (p_src >= 0) p_rec = a.rec[(size_t)p_src * a.rec_stride];
         }
     };
+    // Tiles are handed out by a counter, not strided statically: a workgroup that starts late (its CU held by one of the
+    // side stream's shuffle kernels) then simply takes fewer -- with static striding every launch that overlapped them ran
+    // at the pace of its latest workgroup (in-situ 247 us min, 443 max).  s_tile[(it + k) & 3], k = 0..3: the tiles this
+    // workgroup works on next; rows are fetched one tile ahead, indices two to three.
+    __shared__ int s_tile[4];
+    unsigned* const ctr = a.tile_counter + (DUAL ? 0 : net);
+    if (tid == 0) {       // four consecutive tiles to start with; later ones one at a time (ids only ever grow)
+        const int t0 = (int)atomicAdd(ctr, 4u);
+        s_tile[0] = t0; s_tile[1] = t0 + 1; s_tile[2] = t0 + 2; s_tile[3] = t0 + 3;
+    }
+    __syncthreads();
     if (tid < R) {
-        s.sIdx[tid] = load_idx(pair);
-        s.sIdx[R + tid] = load_idx(pair + n_pairs);
+        s.sIdx[tid] = load_idx(s_tile[0]);
+        s.sIdx[R + tid] = load_idx(s_tile[1]);
     }
     __syncthreads();
     prefetch(s.sIdx);
-    if (tid < R) n_idx = load_idx(pair + 2 * n_pairs);
-    int it = 0;
-    for (int tile = pair; tile < n_tiles; tile += n_pairs, ++it) {
+    if (tid < R) n_idx = load_idx(s_tile[2]);
+    for (int it = 0;; ++it) {
+        const int tile = s_tile[it & 3];
+        if (tile >= n_tiles) break;
+        const int tile3 = s_tile[(it + 3) & 3];
         // ---- land the prefetched tile, start fetching the next one
         float early[16];
         if (EARLY && cb < HB) load_b(early, op_block(a.wop, net, 0, 0, cb, 0, lane));   // layer 1's first weight block, behind the landing
@@ -401,9 +416,13 @@ __global__ __launch_bounds__(256, DUAL ? 2 : 1) void k_mlpw_step(const WideArgs 
         // the next tile's rows are fetched behind this tile's math -- except with three layers, whose accumulators leave
         // no registers to hold them that long: there they are fetched at the end of the tile (latency exposed, ~5 %)
         if (NL < 3) prefetch(s.sIdx + ((it + 1) & 1) * R);
-        if (tid < R) n_idx = load_idx(tile + 3 * n_pairs);
+        if (tid < R) n_idx = load_idx(tile3);
 
         forward_tile<NL, EARLY, DUAL>(a, s, net, cb, HB, DB, early);
+        // the tile after the three already known: asked for here, where this wave has no loads queued behind the atomic
+        // (returns are in order), stored in s_tile at the end of the tile
+        int tile4 = 0;
+        if (tid == 0) tile4 = (int)atomicAdd(ctr, 1u);
 
         // ---- loss lanes (one per row): this net's half of the PPO terms; head outputs become their gradients
         if (lrow < R) {
@@ -537,6 +556,7 @@ __global__ __launch_bounds__(256, DUAL ? 2 : 1) void k_mlpw_step(const WideArgs 
                                   [&](int k, int j) { return s.sX[k * LD_ + cb * 32 + j]; }, lane);
         }
         if (NL >= 3) prefetch(s.sIdx + ((it + 1) & 1) * R);
+        if (tid == 0) s_tile[it & 3] = tile4;               // everyone read this slot at the top of the tile
         __syncthreads();
     }
 
@@ -672,6 +692,7 @@ struct WideWs {
     double* stats;       // (kStatBlocks, 2)
     double* loss_part;   // (kMaxSlabs, 8)
     float* wop;          // kOpFloats
+    unsigned* tile_counter;   // [2] (+ padding to 64 B)
     float* slabs;        // (kMaxSlabs, n_params)
 };
 WideWs wide_ws(void* workspace) {
@@ -680,7 +701,8 @@ WideWs wide_ws(void* workspace) {
     v.stats = reinterpret_cast<double*>(p);
     v.loss_part = v.stats + 2 * kStatBlocks;
     v.wop = reinterpret_cast<float*>(v.loss_part + 8 * kMaxSlabs);
-    v.slabs = v.wop + kOpFloats;
+    v.tile_counter = reinterpret_cast<unsigned*>(v.wop + kOpFloats);
+    v.slabs = reinterpret_cast<float*>(v.tile_counter + 16);
     return v;
 }
 
@@ -723,7 +745,7 @@ int launch_wide(K kernel, bool* attr_done, int grid, size_t lds_bytes, hipStream
 
 extern "C" size_t aurppo_mlp_wide_workspace_bytes(int n_params) {
     // slabs: two both-net workgroups per CU for the narrow shapes (their n_params is small), one pair per two CUs otherwise
-    return sizeof(double) * (2 * kStatBlocks + 8 * kMaxSlabs) + sizeof(float) * (size_t)kOpFloats +
+    return sizeof(double) * (2 * kStatBlocks + 8 * kMaxSlabs) + sizeof(float) * (size_t)kOpFloats + 64 +
            sizeof(float) * (size_t)kMaxSlabs * (size_t)n_params + 64;
 }
 
@@ -749,13 +771,13 @@ extern "C" int aurppo_mlp_wide_ppo_step_f32(const float* obs, const float* actio
     if (rc != AURPPO_OK) return rc;
     a.h = make_hyper(M, clip, ent_coef, vf_coef, norm_adv, vloss_mode);
     const WideWs wv = wide_ws(workspace);
-    a.stats = wv.stats; a.loss_part = wv.loss_part; a.wop = wv.wop; a.slabs = wv.slabs;
+    a.stats = wv.stats; a.loss_part = wv.loss_part; a.wop = wv.wop; a.slabs = wv.slabs; a.tile_counter = wv.tile_counter;
     hipStream_t s = (hipStream_t)stream;
     int sb = (M + 1023) / 1024;
     if (sb > kStatBlocks) sb = kStatBlocks;
     a.n_stat_blocks = sb;
     hipLaunchKernelGGL(k_mlpw_prep, dim3(sb + 96), dim3(256), 0, s, params, a.L, num_layers, D, hidden, wv.wop, a.rec,
-                       a.rec_stride, idx, M, reinterpret_cast<double (*)[2]>(wv.stats), sb);
+                       a.rec_stride, idx, M, reinterpret_cast<double (*)[2]>(wv.stats), sb, wv.tile_counter);
     AURPPO_LAUNCH_CHECK("k_mlpw_prep");
     static int cus_of[kMaxDevices] = {0};
     const int dslot = aurppo_device_slot();
@@ -811,7 +833,7 @@ extern "C" int aurppo_mlp_wide_act_f32(const float* obs, const float* noise, int
     a.wop = wv.wop;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(k_mlpw_prep, dim3(96), dim3(256), 0, s, params, a.L, num_layers, D, hidden, wv.wop,
-                       (const float4*)nullptr, 0, (const int32_t*)nullptr, 0, (double (*)[2]) nullptr, 0);
+                       (const float4*)nullptr, 0, (const int32_t*)nullptr, 0, (double (*)[2]) nullptr, 0, (unsigned*)nullptr);
     AURPPO_LAUNCH_CHECK("k_mlpw_prep");
     const int grid = ((N + R - 1) / R) * a.net_count;
     static bool attr[kMaxDevices][MAXL] = {};
