@@ -3,6 +3,7 @@ int32, contiguous; every call enqueues on torch's CURRENT stream and returns wit
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -321,7 +322,8 @@ def mlp_layout(policy, bucket):
         return None
     if A > MLP_MAX_A or (not cont and A < 2):
         return None
-    fast = NL == 2 and Hd == MLP_HIDDEN and D <= MLP_MAX_D
+    # AURPPO_MLP_FORCE_WIDE=1 (diagnostic): the default shape through K7w too, for a same-box A/B of the two kernels
+    fast = NL == 2 and Hd == MLP_HIDDEN and D <= MLP_MAX_D and os.environ.get("AURPPO_MLP_FORCE_WIDE") != "1"
     if not fast and D > MLP_WIDE_MAX_D:
         return None
     return dict(offsets=seq, n_params=pos, D=D, A=A, continuous=cont, hidden=Hd, num_layers=NL, wide=not fast)
