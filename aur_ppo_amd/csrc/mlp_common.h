@@ -3,6 +3,11 @@
 #pragma once
 #include "ppo_math.h"
 
+// Diagnostic build knob: s_setprio around the MFMA chunks of mma32 (0 = off).
+#ifndef AURPPO_MMA_PRIO
+#define AURPPO_MMA_PRIO 0
+#endif
+
 namespace aurppo_mlp {
 
 constexpr int H = 64;        // hidden width
@@ -68,8 +73,14 @@ __device__ __forceinline__ void mma32(f32x16& acc, FA a_at, FB b_at, int lane) {
                 bv[(c + 1) & 1][u] = b_at(2 * CH * (c + 1) + 2 * u + kk, ij);
             }
         }
+#if AURPPO_MMA_PRIO
+        __builtin_amdgcn_s_setprio(AURPPO_MMA_PRIO);
+#endif
 #pragma unroll
         for (int u = 0; u < CH; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c & 1][u], bv[c & 1][u], acc, 0, 0, 0);
+#if AURPPO_MMA_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         // FENCE pins the pipeline depth to what is written here: without it the scheduler hoists every operand
         // read of the unrolled chain to the top, which costs ~2K registers the two-set kernel does not have.
         if (FENCE) __builtin_amdgcn_sched_barrier(0);
