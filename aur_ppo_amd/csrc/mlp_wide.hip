@@ -15,8 +15,10 @@
 //     32x32 block with four 16-byte loads per lane from L2, one block ahead of the MFMA chain that consumes it;
 //   * activations live in LDS ([32 rows][129]); dZ_l overwrites H_l in place (a wave only ever reads its own column
 //     block of H_l once dZ_l is being formed), so a layer costs one 16.5 KB buffer.
-// Not tuned like k_mlp_step2 (one tile set, static tile striding): it exists so that no supported shape drops to the
-// ~100-launch per-op path.  Measured against that path in DESIGN section 4.7b.
+// When nothing is wider than 64 (two column blocks) a workgroup carries BOTH nets instead -- waves 0,1 the actor's
+// column blocks, waves 2,3 the critic's -- in a geometry (row stride 65, 256 registers) that fits a CU twice, so two
+// independent workgroups overlap each other's epilogues and barriers the way k_mlp_step2's two tile sets do.
+// Tiles are handed out by a counter.  Measured against the per-op path it replaces in DESIGN section 4.3c.
 #include <stdlib.h>
 
 #pragma clang fp contract(fast)
