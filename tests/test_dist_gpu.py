@@ -54,15 +54,16 @@ def _run(agent, full, lo, hi, updates=3):
     return torch.stack(sc)
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, over=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK="0")
     from aur_ppo_amd import dist as D
     from aur_ppo_amd.ppo import ppo
     D.init_from_env(backend="gloo")
     torch.manual_seed(50 + rank)
-    agent = ppo(_params(64))
+    agent = ppo(_params(64, **(over or {})))
     assert agent.device.type == "cuda" and agent._mlp is not None and agent.num_envs == 32 and not agent.use_graph
+    assert agent._mlp["wide"] == bool(over)
     p0 = agent.bucket.flat_param.clone().cpu()
     sc = _run(agent, _rollout(16, 64), agent.env_lo, agent.env_lo + 32)
     torch.save(dict(p0=p0, p1=agent.bucket.flat_param.clone().cpu(), sc=sc, norms=agent._norms.clone().cpu()),
@@ -71,9 +72,10 @@ def _worker(rank, world, port, out_dir):
     torch.distributed.destroy_process_group()
 
 
-def test_two_ranks_on_the_hip_path(tmp_path):
+@pytest.mark.parametrize("over", [None, dict(hidden_dim=128, num_layers=3)], ids=["k7_2x64", "k7w_3x128"])
+def test_two_ranks_on_the_hip_path(tmp_path, over):
     port = _free_port()
-    mp.start_processes(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    mp.start_processes(_worker, args=(2, port, str(tmp_path), over), nprocs=2, join=True, start_method="spawn")
     r0, r1 = (torch.load(tmp_path / f"r{k}.pt") for k in range(2))
     assert torch.equal(r0["p0"], r1["p0"])                    # broadcast at construction
     assert torch.equal(r0["p1"], r1["p1"])                    # same reduced gradients -> same weights, bit for bit
@@ -84,7 +86,7 @@ def test_two_ranks_on_the_hip_path(tmp_path):
     full = _rollout(16, 64)
     agents = []
     for rank in range(2):
-        a = ppo(_params(32, total_timesteps=16 * 32 * 3, hip_graph=False))
+        a = ppo(_params(32, total_timesteps=16 * 32 * 3, hip_graph=False, **(over or {})))
         with torch.no_grad():
             a.bucket.flat_param.copy_(r0["p0"].cuda())
         agents.append(a)
