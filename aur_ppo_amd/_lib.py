@@ -17,7 +17,8 @@ SYMBOLS = (
     "aurppo_mlp_ppo_step_ev_f32", "aurppo_mlp_ppo_minibatch_f32", "aurppo_mlp_ppo_grad_f32", "aurppo_mlp_ppo_apply_f32", "aurppo_pack_records_f32", "aurppo_mlp_act_f32", "aurppo_clip_adam_f32",
     "aurppo_bias_relu_pool2_fwd_f32", "aurppo_bias_relu_pool2_bwd_f32", "aurppo_weighted_batch_sum_f32",
     "aurppo_first_block_fwd_f32", "aurppo_first_block_bwd_f32",
-    "aurppo_mlp_wide_workspace_bytes", "aurppo_mlp_wide_ppo_step_f32", "aurppo_mlp_wide_act_f32",
+    "aurppo_mlp_wide_workspace_bytes", "aurppo_mlp_wide_ppo_step_f32", "aurppo_mlp_wide_ppo_minibatch_f32",
+    "aurppo_mlp_wide_act_f32",
 )
 
 _lib = None
@@ -67,6 +68,8 @@ def load() -> C.CDLL:
     lib.aurppo_mlp_wide_workspace_bytes.restype = C.c_size_t
     lib.aurppo_mlp_wide_ppo_step_f32.argtypes = ([vp] * 4 + [i32] * 6 + [vp, C.POINTER(i32), i32, vp, f64, f64, f64, i32, i32] +
                                                  [vp] * 5)
+    lib.aurppo_mlp_wide_ppo_minibatch_f32.argtypes = ([vp] * 4 + [i32] * 6 + [vp, C.POINTER(i32), i32, vp, f64, f64, f64, i32, i32] +
+                                                      [vp, vp, vp, f64, vp, vp, f64, f64, f64, vp, vp, vp])
     lib.aurppo_mlp_wide_act_f32.argtypes = [vp, vp] + [i32] * 6 + [vp, C.POINTER(i32), i32] + [vp] * 5
     lib.aurppo_mlp_workspace_bytes.argtypes = [i32]
     lib.aurppo_mlp_workspace_bytes.restype = C.c_size_t

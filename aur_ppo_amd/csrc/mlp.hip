@@ -999,15 +999,32 @@ static int mlp_step_impl(const float* obs, const float* actions, const float* re
 }
 
 int aurppo_mlp::launch_mlp_reduce(const float* slabs, const double* loss_part, int n_slabs, int n_params, const PpoHyper& h,
-                                  float* grads, float* out_scalars, hipStream_t s) {
+                                  float* grads, float* out_scalars, hipStream_t s, double* sq_part, float* step_dev,
+                                  unsigned* unused_counter) {
+    // (k_mlp_reduce clears K7's tile counter when it advances the step: the caller names a word it may clear instead)
+    AURPPO_REQUIRE(!step_dev || unused_counter, AURPPO_EINVAL, "launch_mlp_reduce: step_dev without a scratch counter");
     AURPPO_REQUIRE(n_slabs >= 1 && n_slabs <= 2 * kMaxGrid, AURPPO_ESHAPE, "launch_mlp_reduce: n_slabs=%d", n_slabs);
     if (n_slabs <= kMaxGrid)
         hipLaunchKernelGGL(k_mlp_reduce<1>, dim3((n_params + 63) / 64), dim3(1024), 0, s, slabs, loss_part, n_slabs, n_params, h,
-                           grads, out_scalars, (double*)nullptr, (float*)nullptr, (unsigned*)nullptr);
+                           grads, out_scalars, sq_part, step_dev, unused_counter);
     else
         hipLaunchKernelGGL(k_mlp_reduce<2>, dim3((n_params + 63) / 64), dim3(1024), 0, s, slabs, loss_part, n_slabs, n_params, h,
-                           grads, out_scalars, (double*)nullptr, (float*)nullptr, (unsigned*)nullptr);
+                           grads, out_scalars, sq_part, step_dev, unused_counter);
     AURPPO_LAUNCH_CHECK("k_mlp_reduce");
+    return AURPPO_OK;
+}
+
+int aurppo_mlp::launch_adam_tail(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int n_params,
+                                 const double* sq_part, double max_norm, const float* lr_dev, const float* step_dev,
+                                 double beta1, double beta2, double eps, float* out_norm, hipStream_t s) {
+    int nb_upd = (n_params + kThreads * 4 - 1) / (kThreads * 4);
+    if (nb_upd > 64) nb_upd = 64;
+    // no operand-order copy of W1 (offsets past the bucket), no statistics for a next minibatch
+    hipLaunchKernelGGL(k_adam_chain, dim3(nb_upd), dim3(kThreads), 0, s, params, grads, exp_avg, exp_avg_sq, n_params, sq_part,
+                       (n_params + 63) / 64, (float)max_norm, lr_dev, step_dev, beta1, beta2, eps, out_norm, 1.0f, nb_upd, n_params,
+                       n_params, 1, (float*)nullptr, (const float4*)nullptr, 1, (const int32_t*)nullptr, 0,
+                       (double (*)[2]) nullptr);
+    AURPPO_LAUNCH_CHECK("k_adam_chain");
     return AURPPO_OK;
 }
 

@@ -167,7 +167,13 @@ __device__ __forceinline__ f32x16 zero16() {
 size_t mlp_step2_lds_bytes();
 int launch_mlp_step2(const MlpArgs& a, int grid, hipStream_t s);
 // mlp.hip: k_mlp_reduce alone (grads[p] = fixed-order sum over n_slabs slabs, loss scalars folded) -- mlp_wide.hip's tail.
+// sq_part / step_dev != nullptr: also leave the clip's partial sums of squares (one per 64 parameters) and advance the
+// Adam step count -- what launch_adam_tail (k_adam_chain without K7's extras: clip + Adam in one launch) then consumes.
 int launch_mlp_reduce(const float* slabs, const double* loss_part, int n_slabs, int n_params, const PpoHyper& h, float* grads,
-                      float* out_scalars, hipStream_t s);
+                      float* out_scalars, hipStream_t s, double* sq_part = nullptr, float* step_dev = nullptr,
+                      unsigned* scratch_counter = nullptr);   // (with step_dev: a device word the kernel may clear)
+int launch_adam_tail(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int n_params, const double* sq_part,
+                     double max_norm, const float* lr_dev, const float* step_dev, double beta1, double beta2, double eps,
+                     float* out_norm, hipStream_t s);
 
 }  // namespace aurppo_mlp

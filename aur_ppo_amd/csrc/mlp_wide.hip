@@ -696,8 +696,9 @@ struct WideWs {
     float* wop;          // kOpFloats
     unsigned* tile_counter;   // [2] (+ padding to 64 B)
     float* slabs;        // (kMaxSlabs, n_params)
+    double* sq_part;     // (ceil(n_params / 64)) clip partial sums left by k_mlp_reduce
 };
-WideWs wide_ws(void* workspace) {
+WideWs wide_ws(void* workspace, int n_params) {
     WideWs v;
     char* p = reinterpret_cast<char*>(workspace);
     v.stats = reinterpret_cast<double*>(p);
@@ -705,6 +706,7 @@ WideWs wide_ws(void* workspace) {
     v.wop = reinterpret_cast<float*>(v.loss_part + 8 * kMaxSlabs);
     v.tile_counter = reinterpret_cast<unsigned*>(v.wop + kOpFloats);
     v.slabs = reinterpret_cast<float*>(v.tile_counter + 16);
+    v.sq_part = reinterpret_cast<double*>(v.slabs + (((size_t)kMaxSlabs * (size_t)n_params + 15) / 16) * 16);
     return v;
 }
 
@@ -748,15 +750,27 @@ int launch_wide(K kernel, bool* attr_done, int grid, size_t lds_bytes, hipStream
 extern "C" size_t aurppo_mlp_wide_workspace_bytes(int n_params) {
     // slabs: two both-net workgroups per CU for the narrow shapes (their n_params is small), one pair per two CUs otherwise
     return sizeof(double) * (2 * kStatBlocks + 8 * kMaxSlabs) + sizeof(float) * (size_t)kOpFloats + 64 +
-           sizeof(float) * (size_t)kMaxSlabs * (size_t)n_params + 64;
+           sizeof(float) * (size_t)kMaxSlabs * (size_t)n_params + 64 + sizeof(double) * (size_t)((n_params + 63) / 64) + 64;
 }
 
-extern "C" int aurppo_mlp_wide_ppo_step_f32(const float* obs, const float* actions, const float* rec, const int32_t* idx, int M,
-                                            int D, int A, int continuous, int hidden, int num_layers, const float* params,
-                                            const int* layout_h, int n_params, float* grads, double clip, double ent_coef,
-                                            double vf_coef, int norm_adv, int vloss_mode, float* out_scalars, void* workspace,
-                                            void* stream, void* ev_begin, void* ev_end) {
-    const char* who = "aurppo_mlp_wide_ppo_step_f32";
+namespace {
+struct WideTail {   // the optimizer half of aurppo_mlp_wide_ppo_minibatch_f32
+    float* params_rw;
+    float* exp_avg;
+    float* exp_avg_sq;
+    double max_norm;
+    const float* lr_dev;
+    float* step_dev;
+    double beta1, beta2, eps;
+    float* out_norm;
+};
+}  // namespace
+
+static int wide_step_impl(const float* obs, const float* actions, const float* rec, const int32_t* idx, int M, int D, int A,
+                          int continuous, int hidden, int num_layers, const float* params, const int* layout_h, int n_params,
+                          float* grads, double clip, double ent_coef, double vf_coef, int norm_adv, int vloss_mode,
+                          float* out_scalars, void* workspace, void* stream, void* ev_begin, void* ev_end, const WideTail* tail,
+                          const char* who) {
     AURPPO_REQUIRE(obs && rec && idx && params && layout_h && grads && out_scalars && workspace, AURPPO_EINVAL, "%s: null pointer", who);
     AURPPO_REQUIRE(actions || (continuous ? A : 1) <= 12, AURPPO_ESHAPE,
                    "%s: packed records hold at most 12 action floats (action_dim=%d)", who, A);
@@ -772,7 +786,7 @@ extern "C" int aurppo_mlp_wide_ppo_step_f32(const float* obs, const float* actio
     rc = fill_layout(a.L, layout_h, num_layers, continuous, n_params, who);
     if (rc != AURPPO_OK) return rc;
     a.h = make_hyper(M, clip, ent_coef, vf_coef, norm_adv, vloss_mode);
-    const WideWs wv = wide_ws(workspace);
+    const WideWs wv = wide_ws(workspace, n_params);
     a.stats = wv.stats; a.loss_part = wv.loss_part; a.wop = wv.wop; a.slabs = wv.slabs; a.tile_counter = wv.tile_counter;
     hipStream_t s = (hipStream_t)stream;
     int sb = (M + 1023) / 1024;
@@ -811,7 +825,39 @@ extern "C" int aurppo_mlp_wide_ppo_step_f32(const float* obs, const float* actio
     if (rc != AURPPO_OK) return rc;
     AURPPO_LAUNCH_CHECK("k_mlpw_step");
     if (ev_end) AURPPO_HIP_TRY(hipEventRecord((hipEvent_t)ev_end, s));
-    return launch_mlp_reduce(wv.slabs, wv.loss_part, pairs, n_params, a.h, grads, out_scalars, s);
+    if (!tail) return launch_mlp_reduce(wv.slabs, wv.loss_part, pairs, n_params, a.h, grads, out_scalars, s);
+    rc = launch_mlp_reduce(wv.slabs, wv.loss_part, pairs, n_params, a.h, grads, out_scalars, s, wv.sq_part, tail->step_dev,
+                           wv.tile_counter + 8);
+    if (rc != AURPPO_OK) return rc;
+    return launch_adam_tail(tail->params_rw, grads, tail->exp_avg, tail->exp_avg_sq, n_params, wv.sq_part, tail->max_norm,
+                            tail->lr_dev, tail->step_dev, tail->beta1, tail->beta2, tail->eps, tail->out_norm, s);
+}
+
+extern "C" int aurppo_mlp_wide_ppo_step_f32(const float* obs, const float* actions, const float* rec, const int32_t* idx, int M,
+                                            int D, int A, int continuous, int hidden, int num_layers, const float* params,
+                                            const int* layout_h, int n_params, float* grads, double clip, double ent_coef,
+                                            double vf_coef, int norm_adv, int vloss_mode, float* out_scalars, void* workspace,
+                                            void* stream, void* ev_begin, void* ev_end) {
+    return wide_step_impl(obs, actions, rec, idx, M, D, A, continuous, hidden, num_layers, params, layout_h, n_params, grads, clip,
+                          ent_coef, vf_coef, norm_adv, vloss_mode, out_scalars, workspace, stream, ev_begin, ev_end, nullptr,
+                          "aurppo_mlp_wide_ppo_step_f32");
+}
+
+extern "C" int aurppo_mlp_wide_ppo_minibatch_f32(const float* obs, const float* actions, const float* rec, const int32_t* idx,
+                                                 int M, int D, int A, int continuous, int hidden, int num_layers, float* params,
+                                                 const int* layout_h, int n_params, float* grads, double clip, double ent_coef,
+                                                 double vf_coef, int norm_adv, int vloss_mode, float* out_scalars,
+                                                 float* exp_avg, float* exp_avg_sq, double max_norm, const float* lr_dev,
+                                                 float* step_dev, double beta1, double beta2, double eps, float* out_norm,
+                                                 void* workspace, void* stream) {
+    AURPPO_REQUIRE(exp_avg && exp_avg_sq && lr_dev && step_dev && out_norm, AURPPO_EINVAL,
+                   "aurppo_mlp_wide_ppo_minibatch_f32: null optimizer pointer");
+    WideTail t;
+    t.params_rw = params; t.exp_avg = exp_avg; t.exp_avg_sq = exp_avg_sq; t.max_norm = max_norm; t.lr_dev = lr_dev;
+    t.step_dev = step_dev; t.beta1 = beta1; t.beta2 = beta2; t.eps = eps; t.out_norm = out_norm;
+    return wide_step_impl(obs, actions, rec, idx, M, D, A, continuous, hidden, num_layers, params, layout_h, n_params, grads, clip,
+                          ent_coef, vf_coef, norm_adv, vloss_mode, out_scalars, workspace, stream, nullptr, nullptr, &t,
+                          "aurppo_mlp_wide_ppo_minibatch_f32");
 }
 
 extern "C" int aurppo_mlp_wide_act_f32(const float* obs, const float* noise, int N, int D, int A, int continuous, int hidden,
@@ -831,7 +877,7 @@ extern "C" int aurppo_mlp_wide_act_f32(const float* obs, const float* noise, int
     a.net_count = noise ? 2 : 1;
     rc = fill_layout(a.L, layout_h, num_layers, continuous, n_params, who);
     if (rc != AURPPO_OK) return rc;
-    const WideWs wv = wide_ws(workspace);
+    const WideWs wv = wide_ws(workspace, n_params);
     a.wop = wv.wop;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(k_mlpw_prep, dim3(96), dim3(256), 0, s, params, a.L, num_layers, D, hidden, wv.wop,

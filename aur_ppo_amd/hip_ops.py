@@ -427,10 +427,20 @@ def mlp_ppo_minibatch(obs, actions, rec, idx, flat_param, layout, flat_grad, cli
     cont = layout.get("continuous", True)
     if not _mlp_buffers_ok(obs, actions, rec, layout):
         raise ValueError("mlp_ppo_minibatch: buffer shapes do not match the policy")
-    _wide_only_step(layout, "mlp_ppo_minibatch")
     if min(flat_param.numel(), flat_grad.numel(), exp_avg.numel(), exp_avg_sq.numel()) < n:
         raise ValueError("mlp_ppo_minibatch: the flat bucket is smaller than the policy")
     # alignment padding past n_params is left alone: its gradient is never written, so clip and Adam are no-ops there
+    if layout.get("wide"):
+        # K7w: prepare + step + slab reduce + clip/Adam, four launches (no hand-over between calls: next_idx / chained unused)
+        ws = _workspace("mlp_wide", lib.aurppo_mlp_wide_workspace_bytes(n), obs.device)
+        lay = (C.c_int * len(layout["offsets"]))(*layout["offsets"])
+        _check(lib.aurppo_mlp_wide_ppo_minibatch_f32(
+            _ptr(obs), _optr(actions), _ptr(rec), _ptr(idx, torch.int32), M, D, A, int(cont), layout["hidden"], layout["num_layers"],
+            _ptr(flat_param), lay, n, _ptr(flat_grad), float(clip), float(ent_coef), float(vf_coef), int(bool(norm_adv)),
+            int(vloss_mode), _ptr(out_scalars), _ptr(exp_avg), _ptr(exp_avg_sq), float(max_norm), _ptr(lr_dev), _ptr(step_dev),
+            float(betas[0]), float(betas[1]), float(eps), _ptr(out_norm), C.c_void_p(ws.data_ptr()), _stream()),
+            "aurppo_mlp_wide_ppo_minibatch_f32")
+        return out_scalars
     ws = _workspace("mlp", lib.aurppo_mlp_workspace_bytes(n), obs.device)
     lay = (C.c_int * 13)(*layout["offsets"])
     _check(lib.aurppo_mlp_ppo_minibatch_f32(

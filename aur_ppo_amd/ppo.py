@@ -383,7 +383,7 @@ class ppo(FlatAdamMixin):
         step = 0
         # single process, MLP policy, fused Adam over exactly the policy's bucket: K7 + clip + Adam chained, three
         # launches per minibatch (each call also prepares the statistics of the slice that follows it)
-        chain = (packed and self._mlp is not None and not self._mlp.get("wide") and not self._dp and self._fused_adam
+        chain = (packed and self._mlp is not None and not self._dp and self._fused_adam
                  and self._bucket_is_policy and hasattr(ops, "mlp_ppo_minibatch"))
         # one process per GPU: the same chain in two halves around the gradient all-reduce (SUM; the 1/W rides in the
         # apply kernel), three launches + one collective per minibatch

@@ -211,3 +211,45 @@ def test_rollout_with_a_wide_policy_goes_through_k8w_and_trains():
     torch.cuda.synchronize()
     assert a.last_update["scalars"].shape == (16, 9) and np.isfinite(a.last_update["scalars"]).all()
     assert torch.isfinite(a.bucket.flat_param).all()
+
+
+@pytest.mark.parametrize("hidden,layers,D", [(128, 3, 64), (64, 3, 24), (32, 1, 8)])
+def test_wide_minibatch_matches_step_then_clip_adam(hidden, layers, D):
+    """aurppo_mlp_wide_ppo_minibatch_f32 over a run of minibatches == the same run as aurppo_mlp_wide_ppo_step_f32 +
+    aurppo_clip_adam_f32 pairs: parameters, moments, loss scalars, norms and the Adam step count."""
+    T, N, A, M = 16, 64, 6, 300      # B = 1024: three full slices and a ragged tail
+    H, pol, bucket, obs, act, rec = _setup(T, N, D, A, hidden, layers, seed=3)
+    lay = H.mlp_layout(pol, bucket)
+    nb = bucket.flat_param.numel()
+    perm = torch.randperm(T * N, device="cuda").int()
+    slices = [perm[s:s + M] for s in range(0, T * N, M)]
+    p0 = bucket.flat_param.clone()
+
+    def run(chained):
+        bucket.flat_param.copy_(p0)
+        m, v = torch.zeros(nb, device="cuda"), torch.zeros(nb, device="cuda")
+        lr, t = torch.full((1,), 3e-3, device="cuda"), torch.zeros(1, device="cuda")
+        sc = torch.zeros(len(slices) * 2, 9, device="cuda")
+        norms = torch.zeros(len(slices) * 2, device="cuda")
+        g = torch.zeros(nb, device="cuda")
+        k = 0
+        for _rep in range(2):
+            for idx in slices:
+                if chained:
+                    H.mlp_ppo_minibatch(obs, act, rec, idx, bucket.flat_param, lay, g, 0.2, 0.01, 0.5, True, 1, sc[k], m, v, lr, t,
+                                        0.5, (0.9, 0.999), 1e-5, norms[k:k + 1])
+                else:
+                    H.mlp_ppo_step(obs, act, rec, idx, bucket.flat_param, lay, g, 0.2, 0.01, 0.5, True, 1, sc[k])
+                    H.clip_adam_(bucket.flat_param, g, m, v, lr, t, 0.5, None, (0.9, 0.999), 1e-5, norms[k:k + 1])
+                k += 1
+        torch.cuda.synchronize()
+        return bucket.flat_param.clone(), m, v, sc, norms, float(t)
+
+    ref = run(False)
+    got = run(True)
+    assert got[5] == ref[5] == 2 * len(slices)
+    torch.testing.assert_close(got[4], ref[4], rtol=1e-6, atol=0)
+    torch.testing.assert_close(got[3], ref[3], rtol=2e-5, atol=2e-6)
+    for a_, b_ in zip(got[:3], ref[:3]):
+        torch.testing.assert_close(a_, b_, rtol=1e-4, atol=1e-6)
+    assert float((ref[0] - p0).abs().max()) > 1e-3
