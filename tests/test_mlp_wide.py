@@ -196,10 +196,11 @@ def test_full_update_with_a_wide_policy_matches_oracle(hidden, layers, Dm, launc
     cols = [0, 1, 2, 3, 4, 5, 7, 8]
     np.testing.assert_allclose(got[:, cols], res["scalars"][:, cols], rtol=1e-4, atol=1e-5)
     assert np.abs(got[:, 6] - res["scalars"][:, 6]).max() <= 1.5 / agent.minibatch_size
-    # 1e-5 absolute: tiles reach workgroups through a counter, a gradient's last bits depend on the launch, and Adam's step
-    # has sensitivity lr / eps = 30 to an element far below eps (tools/update_repeatability.py: two GPU runs end up to 9e-6 apart)
+    # 2e-5 absolute: tiles reach workgroups through a counter, a gradient's last bits depend on the launch, and Adam's step
+    # has sensitivity lr / eps = 30 to an element far below eps (tools/update_repeatability.py: two GPU runs of one update
+    # end up to 9e-6 apart at the bench size; bound 16 steps x lr x 4e-7 max|g| / eps)
     for k, v in agent.policy.state_dict().items():
-        np.testing.assert_allclose(v.cpu().numpy(), net.state_dict()[k].numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
+        np.testing.assert_allclose(v.cpu().numpy(), net.state_dict()[k].numpy(), rtol=1e-4, atol=2e-5, err_msg=k)
 
 
 def test_rollout_with_a_wide_policy_goes_through_k8w_and_trains():
