@@ -15,9 +15,39 @@ void aurppo_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+namespace {
+int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+AurppoKnobs parse_knobs() {
+    AurppoKnobs k;
+    k.k7_variant = env_int("AURPPO_K7_VARIANT", 2);
+    k.k7_spare_cus = env_int("AURPPO_MLP_SPARE_CUS", 8);
+    k.static_tiles = env_int("AURPPO_STATIC_TILES", 0);
+    k.k2_one_stream = env_int("AURPPO_K2_ONE_STREAM", 0);
+    k.k2_link_wgs = env_int("AURPPO_K2_LINK_WGS", 48);
+    k.k2_resolve_wgs = env_int("AURPPO_K2_RESOLVE_WGS", 256);
+    k.k2_post_stream = env_int("AURPPO_K2_POST_STREAM", 0);
+    k.k2_fill_wgs = env_int("AURPPO_K2_FILL_WGS", 0);
+    k.gather_unroll = env_int("AURPPO_GATHER_UNROLL", 0);
+    k.gather_rows = env_int("AURPPO_GATHER_ROWS", 0);
+    return k;
+}
+}  // namespace
+
+const AurppoKnobs& aurppo_knobs() {
+    static const bool live = env_int("AURPPO_TEST_KNOBS", 0) == 1;
+    static thread_local AurppoKnobs k = parse_knobs();
+    if (live) k = parse_knobs();
+    return k;
+}
+
 extern "C" const char* aurppo_last_error(void) { return g_err; }
 
 extern "C" int aurppo_version(void) { return AURPPO_VERSION; }
+
+extern "C" int aurppo_k7_variant(void) { return aurppo_knobs().k7_variant == 3 ? 3 : 2; }
 
 extern "C" int aurppo_device_count(void) {
     int n = 0;

@@ -44,12 +44,23 @@ static inline int aurppo_device_slot() {
     if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) d = 0;
     return d;
 }
-// Diagnostic knobs (AURPPO_MLP_VARIANT ...) are read once per process; with AURPPO_TEST_KNOBS=1 (tests/conftest.py)
-// they are re-read on every call so that one test process can run both variants.
-static inline bool aurppo_live_knobs() {
-    static const bool live = [] { const char* e = getenv("AURPPO_TEST_KNOBS"); return e && *e == '1'; }();
-    return live;
-}
+// Diagnostic knobs.  Every environment variable the library looks at is parsed in ONE place (api.hip) into this struct,
+// once per process -- or on every call when AURPPO_TEST_KNOBS=1 (tests/conftest.py), so that one test process can flip
+// them.  None of them changes results beyond summation order; the defaults are the product configuration.
+struct AurppoKnobs {
+    int k7_variant;        // AURPPO_K7_VARIANT: 2 = f32 MFMA k_mlp_step2, 3 = 3 x bf16-split MFMA k_mlp_step3 (mlp3.hip); default: see api.hip
+    int k7_spare_cus;      // AURPPO_MLP_SPARE_CUS: CUs K7 / K7w leave to the side stream's shuffle kernels (default 8)
+    int static_tiles;      // AURPPO_STATIC_TILES=1: K7 / K7w deal tiles by static stride instead of through the counter, which
+                           // fixes the order of every sum (bit-reproducible gradients; tests/test_determinism.py)
+    int k2_one_stream;     // AURPPO_K2_ONE_STREAM=1: twist and resolves on the caller's stream (everything serial)
+    int k2_link_wgs;       // AURPPO_K2_LINK_WGS: workgroups of k_fy_link (default 48; 0 = one per 256 positions)
+    int k2_resolve_wgs;    // AURPPO_K2_RESOLVE_WGS: workgroups of k_fy_resolve (default 256; 0 = one per 256 positions)
+    int k2_post_stream;    // AURPPO_K2_POST_STREAM=1: link + resolve on a third stream of the handle
+    int k2_fill_wgs;       // AURPPO_K2_FILL_WGS: workgroups of the parallel twist (default: see shuffle.hip; 1 = the serial twist)
+    int gather_unroll;     // AURPPO_GATHER_UNROLL (0 = by row width)
+    int gather_rows;       // AURPPO_GATHER_ROWS (0 = by row width)
+};
+const AurppoKnobs& aurppo_knobs();
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

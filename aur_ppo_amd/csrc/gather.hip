@@ -139,11 +139,6 @@ __global__ __launch_bounds__(256) void k_gather(const int32_t* __restrict__ idx,
     }
 }
 
-int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return (v && *v) ? atoi(v) : dflt;
-}
-
 template <int UNROLL>
 void launch_nv(int nv, int grid, hipStream_t st, const int32_t* idx, const GatherArgs& a) {
     switch (nv) {
@@ -172,8 +167,7 @@ extern "C" int aurppo_gather_f32(const int32_t* idx, int M, const float* const* 
     // (rocprof: 24.2 us vs 26.4 / 28.3 us for UNROLL 2 / 4); a persistent variant that prefetched the
     // next tile's indices measured no better (24.8-27.9 us) and was dropped.  Rows wider than one lane
     // group (images) need the 4-deep unroll to keep loads in flight inside their chunk loop.
-    static const int kUnroll = env_int("AURPPO_GATHER_UNROLL", 0);
-    static const int kRowsOverride = env_int("AURPPO_GATHER_ROWS", 0);
+    const int kUnroll = aurppo_knobs().gather_unroll, kRowsOverride = aurppo_knobs().gather_rows;
     int widest = 1;
     for (int s = 0; s < n_streams; ++s) widest = row_elems_h[s] > widest ? row_elems_h[s] : widest;
     int unroll = widest > 256 ? 4 : 1;

@@ -1,40 +1,20 @@
-// K7: one fused PPO minibatch step for the reference's MLP actor-critic (src/models/actor_critic.py:8-51
-// over src/nets/nets.py:19-53: two Tanh hidden layers of 64, Gaussian head with a state-independent
-// log-std) -- gather (a7) + policy/value forward (a8) + advantage normalisation and clipped-surrogate
-// loss (a9/a10) + back-propagation, producing the flat parameter-gradient bucket and the 9 loss scalars.
+// K7 host side + the small kernels around the fused PPO minibatch step for the reference's MLP actor-critic
+// (src/models/actor_critic.py:8-51 over src/nets/nets.py:19-53: two Tanh hidden layers of 64, Gaussian head with a
+// state-independent log-std or Categorical head): gather (a7) + policy/value forward (a8) + advantage normalisation and
+// clipped-surrogate loss (a9/a10) + back-propagation, producing the flat parameter-gradient bucket and the 9 loss scalars.
 //
-// Why: rocprof of the per-op path (profiles/r01) shows ~100 small kernels per minibatch moving ~2 GB
-// through HBM for 12 GFLOP of work.  Here a minibatch reads each sample's observation row, action row
-// and 16-B record ONCE (through the permutation, so K3's copy disappears too) and writes only
-// per-workgroup gradient slabs; every activation lives in LDS / registers.
-//
-// Structure (gfx950, 256 threads = 4 waves, one workgroup per CU, persistent over row tiles of 32):
-//   * weights of both nets sit in LDS for the whole launch, each stored ONCE as [out][in] with row
-//     stride in+1: the forward pass reads it column-wise (B = W^T), the backward pass row-wise
-//     (B = W); with the odd stride both patterns are bank-conflict free for ds_read_b32.
-//   * waves 0,1 = actor, waves 2,3 = critic; inside a net a wave owns one 32-column half of each
-//     64-wide layer, i.e. one 32x32 accumulator of v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate:
-//     a k-ordered fmaf chain, so results match an fp32 reference to rounding).
-//   * per tile: gather X -> L1 -> tanh -> L2 -> tanh -> head -> (32 lanes) Gaussian log-prob, PPO
-//     terms, d mu / d v -> dH2 -> dZ2 -> dW3,dW2 -> dH1 -> dZ1 -> dW1; weight/bias gradient
-//     accumulators persist in registers across tiles and are written once as a slab.
-//   * a second kernel sums the slabs in fixed order (deterministic) and folds the loss scalars.
-// Compute bound: ~94 kFLOP per sample -> 12.3 GFLOP per 131072-sample minibatch, 79 us at the
-// 157 TFLOP/s fp32 MFMA peak; HBM traffic 39 MB (5 us).
+// Why: rocprof of the per-op path (profiles/r01) shows ~100 small kernels per minibatch moving ~2 GB through HBM for
+// 11 GFLOP of work.  A minibatch reads each sample's observation row and its packed record ONCE (through the
+// permutation, so K3's copy disappears too) and writes only per-workgroup gradient slabs; every activation lives in
+// LDS / registers.  The step kernels themselves: mlp2.hip (k_mlp_step2, fp32 MFMA) and mlp3.hip (k_mlp_step3, the same
+// step on bf16 MFMAs over three-way bf16 splits of every fp32 operand).  Here:
+//   * k_adv_stats_idx  -- advantage partial sums of a minibatch + operand-order copies of the weights the step streams;
+//   * k_mlp_reduce     -- sums the slabs in fixed order (deterministic), folds the loss scalars, leaves the clip's partial sums;
+//   * k_adam_chain     -- clip + Adam, refreshes the operand-order copies, prepares the next minibatch's statistics;
+//   * k_mlp_act (K8)   -- the rollout step (forward only);
+//   * k_pack_rec64     -- record + action row in one 64-B line per sample.
+// (Round 1-2's one-tile-set kernel k_mlp_step -- 4 waves, 221 us -- was kept for A/B until round 3 and is gone.)
 #include <stdlib.h>
-
-// Diagnostic build only (tools/mlp_stamps.sh): -DAURPPO_MLP_STAMPS adds s_memtime stamps per phase and
-// dumps wave 0's cycle shares to the tail of the workspace.  The product library is built without it.
-#ifdef AURPPO_MLP_STAMPS
-#define STAMP(k)                                                      \
-    do {                                                              \
-        const unsigned long long t__ = __builtin_readcyclecounter();  \
-        st_acc[k] += t__ - st_last;                                   \
-        st_last = t__;                                                \
-    } while (0)
-#else
-#define STAMP(k) do { } while (0)
-#endif
 
 #include "adam_math.h"
 #include "mlp_common.h"
@@ -72,404 +52,6 @@ __global__ __launch_bounds__(256) void k_adv_stats_idx(const float4* __restrict_
         stats[blockIdx.x][0] = bs;
         stats[blockIdx.x][1] = bq;
     }
-}
-
-__global__ __launch_bounds__(256, 1) void k_mlp_step(const MlpArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    // ---- LDS carve-up (floats)
-    float* sX = lds;                         // [R][LD]
-    float* sH1 = sX + R * LD;                // [2][R][LD]
-    float* sH2 = sH1 + 2 * R * LD;           // [2][R][LD]
-    float* sdZ = sH2 + 2 * R * LD;           // [2][R][LD]
-    float* sW1 = sdZ + 2 * R * LD;           // [2][H][LD]   W1[out][in<D]
-    float* sW2 = sW1 + 2 * H * LD;           // [2][H][LD]
-    float* sW3 = sW2 + 2 * H * LD;           // [2][AP][LD]  head, rows >= out_dim are zero
-    float* sOut = sW3 + 2 * AP * LD;         // [2][R][LDO]  head outputs, then d(head outputs)
-    float* sB1 = sOut + 2 * R * LDO;         // [2][H]
-    float* sB2 = sB1 + 2 * H;                // [2][H]
-    float* sB3 = sB2 + 2 * H;                // [2][AP]
-    float* sLs = sB3 + 2 * AP;               // [AP] logstd
-    float* sIvar = sLs + AP;                 // [AP] 1 / sigma^2
-    float* sAct = sIvar + AP;                // [R][LDO] this tile's action rows
-    float* sDls = sAct + R * LDO;            // [R][LDO] this tile's per-sample d logstd terms
-    float4* sRec = reinterpret_cast<float4*>(sDls + R * LDO);   // [R] this tile's records (16-B aligned: see lds_bytes)
-    int* sSrc = reinterpret_cast<int*>(sRec + R);               // [R] this tile's sample index (-1: padding row)
-    int* sIdx = sSrc + R;                                       // [2][R] sample indices of the next two tiles
-    __shared__ double s_red[8][kThreads / kWave];
-    __shared__ float s_mean, s_std;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int net = wave >> 1, cb = wave & 1;   // net 0 actor / 1 critic; column half of the 64-wide layers
-    const int D = a.D, A = a.A;
-    const int AW = a.continuous ? a.A : 1;    // floats per stored action row
-    const int out_dim[2] = {A, 1};
-
-    // ---- stage weights (once per launch); layer 1 always runs K = 64, so columns >= D stay zero
-    for (int e = tid; e < R * LD; e += kThreads) sX[e] = 0.0f;
-    for (int e = tid; e < 2 * H * LD; e += kThreads) sW1[e] = 0.0f;
-    __syncthreads();
-    for (int n = 0; n < 2; ++n) {
-        for (int e = tid; e < H * D; e += kThreads) sW1[(n * H + e / D) * LD + e % D] = a.params[a.L.w1[n] + e];
-        for (int e = tid; e < H * H; e += kThreads) sW2[(n * H + e / H) * LD + e % H] = a.params[a.L.w2[n] + e];
-        for (int e = tid; e < AP * H; e += kThreads) {
-            const int o = e / H, i = e % H;
-            const float w3v = a.params[a.L.w3[n] + (o < out_dim[n] ? o : 0) * H + i];
-            sW3[(n * AP + o) * LD + i] = o < out_dim[n] ? w3v : 0.0f;
-        }
-        for (int e = tid; e < H; e += kThreads) {
-            sB1[n * H + e] = a.params[a.L.b1[n] + e];
-            sB2[n * H + e] = a.params[a.L.b2[n] + e];
-        }
-        for (int e = tid; e < AP; e += kThreads) sB3[n * AP + e] = e < out_dim[n] ? a.params[a.L.b3[n] + e] : 0.0f;
-    }
-    for (int e = tid; e < AP; e += kThreads) {
-        const float ls = (a.continuous && e < A) ? a.params[a.L.logstd + e] : 0.0f;
-        const float sd = expf(ls);
-        sLs[e] = ls;
-        sIvar[e] = 1.0f / (sd * sd);
-    }
-    for (int e = tid; e < R * LDO; e += kThreads) sDls[e] = 0.0f;
-    // ---- minibatch advantage statistics from the partials (same order in every workgroup)
-    {
-        double s = 0.0, q = 0.0;
-        for (int b = tid; b < a.n_stat_blocks; b += kThreads) {
-            s += a.stats[2 * b];
-            q += a.stats[2 * b + 1];
-        }
-        const double ts = block_sum<kThreads / kWave>(s, s_red[0]);
-        const double tq = block_sum<kThreads / kWave>(q, s_red[1]);
-        if (tid == 0) {
-            const double m = ts / (double)a.h.M;
-            double var = (tq - ts * m) / (double)(a.h.M - 1);
-            if (var < 0.0) var = 0.0;
-            s_mean = (float)m;
-            s_std = (float)sqrt(var);
-        }
-    }
-    __syncthreads();
-    const float mean = s_mean, denom = s_std + 1e-8f;
-    const float invM = 1.0f / (float)a.h.M;
-    const float g_ent = -a.h.ent_coef * invM;
-
-    // ---- persistent accumulators (registers)
-    f32x16 gW1[2] = {zero16(), zero16()};  // dW1 blocks (out-block ob = 0,1 ; in-block = cb)
-    f32x16 gW2[2] = {zero16(), zero16()};  // dW2 blocks (ob = 0,1 ; in-block = cb)
-    f32x16 gW3 = zero16();                  // dW3 block  (rows < out_dim ; in-block = cb)
-    float gb1 = 0.0f, gb2 = 0.0f;           // lanes 0..31: bias grads of columns cb*32 + lane
-    // loss lanes (tid < R): per-row sums and head-side gradients
-    double l_pg = 0, l_vl = 0, l_ent = 0, l_okl = 0, l_kl = 0, l_cf = 0;
-    float g_b3c = 0.0f;
-    float g_head = 0.0f;   // wave 1: lanes 0..15 d b3[actor], lanes 16..31 d logstd
-
-#ifdef AURPPO_MLP_STAMPS
-    unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long st_last = __builtin_readcyclecounter();
-#endif
-    const int n_tiles = (a.h.M + R - 1) / R;
-    constexpr int XPT = R * H / kThreads;   // X elements per thread per tile (8)
-    constexpr int APT = R * AP / kThreads;  // action elements per thread per tile (2)
-    float xr[XPT];                          // next tile's observation rows, in flight
-    float ar[APT];
-    float4 p_rec = make_float4(0.f, 0.f, 0.f, 0.f);
-    int p_src = -1, n_idx = -1;
-    // tile-invariant element coordinates of this thread's staging slots
-    int x_row[XPT], x_col[XPT], a_row[APT], a_col[APT];
-#pragma unroll
-    for (int u = 0; u < XPT; ++u) {
-        const int e = tid + u * kThreads;
-        x_row[u] = e < R * D ? e / D : -1;
-        x_col[u] = e < R * D ? e % D : 0;
-    }
-#pragma unroll
-    for (int u = 0; u < APT; ++u) {
-        const int e = tid + u * kThreads;
-        a_row[u] = (e % AP) < AW ? e / AP : -1;
-        a_col[u] = e % AP;
-    }
-    // Sample indices are staged in LDS one tile AHEAD of the rows they address, so the row loads below
-    // issue from an LDS read instead of waiting on their own global idx load.
-    auto load_idx = [&](int tile) -> int {   // lanes < R
-        const int m = tile * R + tid;
-        return (tile < n_tiles && m < a.h.M) ? a.idx[m] : -1;
-    };
-    // packed records (actions == nullptr): a sample's action row sits behind its 16-B record in one 64-B line
-    const float* const act_base = a.actions ? a.actions : reinterpret_cast<const float*>(a.rec) + 4;
-    const int act_stride = a.actions ? AW : 16;
-    auto prefetch = [&](const int* sidx) {
-#pragma unroll
-        for (int u = 0; u < XPT; ++u) {
-            const int src = x_row[u] >= 0 ? sidx[x_row[u]] : -1;
-            xr[u] = src >= 0 ? a.obs[(size_t)src * D + x_col[u]] : 0.0f;
-        }
-#pragma unroll
-        for (int u = 0; u < APT; ++u) {
-            const int src = a_row[u] >= 0 ? sidx[a_row[u]] : -1;
-            ar[u] = src >= 0 ? act_base[(size_t)src * act_stride + a_col[u]] : 0.0f;
-        }
-        if (tid < R) {
-            p_src = sidx[tid];
-            if (p_src >= 0) p_rec = a.rec[(size_t)p_src * a.rec_stride];
-        }
-    };
-    const int stride = gridDim.x;
-    if (tid < R) {
-        sIdx[tid] = load_idx(blockIdx.x);
-        sIdx[R + tid] = load_idx(blockIdx.x + stride);
-    }
-    __syncthreads();
-    prefetch(sIdx);
-    if (tid < R) n_idx = load_idx(blockIdx.x + 2 * stride);
-    int it = 0;
-    for (int tile = blockIdx.x; tile < n_tiles; tile += stride, ++it) {
-        // ---- land the prefetched tile in LDS, then start fetching the next one behind this tile's math
-#pragma unroll
-        for (int u = 0; u < XPT; ++u)
-            if (x_row[u] >= 0) sX[x_row[u] * LD + x_col[u]] = xr[u];
-#pragma unroll
-        for (int u = 0; u < APT; ++u) {
-            const int e = tid + u * kThreads;
-            sAct[(e / AP) * LDO + (e % AP)] = ar[u];
-        }
-        if (tid < R) {
-            sSrc[tid] = p_src;
-            sRec[tid] = p_rec;
-            sIdx[(it & 1) * R + tid] = n_idx;     // indices of tile it+2 replace those of tile it (consumed)
-        }
-        __syncthreads();
-        STAMP(0);
-        prefetch(sIdx + ((it + 1) & 1) * R);          // rows of tile it+1 (indices already in LDS)
-        if (tid < R) n_idx = load_idx(tile + 3 * stride);   // will be stored at the top of tile it+1 as tile it+3's
-        STAMP(1);
-        // ---- layer 1: Z1 = X W1^T + b1, H1 = tanh(Z1)
-        {
-            f32x16 acc = zero16();
-            const float* W = sW1 + (net * H + cb * 32) * LD;
-            mma32<H>(acc, [&](int i, int k) { return sX[i * LD + k]; }, [&](int k, int j) { return W[j * LD + k]; });
-            const int col = cb * 32 + (lane & 31);
-            const float bias = sB1[net * H + col];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) sH1[(net * R + acc_row(e, lane)) * LD + col] = tanh_fast(acc[e] + bias);
-        }
-        __syncthreads();
-        STAMP(2);
-        // ---- layer 2
-        {
-            f32x16 acc = zero16();
-            const float* W = sW2 + (net * H + cb * 32) * LD;
-            const float* Hin = sH1 + net * R * LD;
-            mma32<H>(acc, [&](int i, int k) { return Hin[i * LD + k]; }, [&](int k, int j) { return W[j * LD + k]; });
-            const int col = cb * 32 + (lane & 31);
-            const float bias = sB2[net * H + col];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) sH2[(net * R + acc_row(e, lane)) * LD + col] = tanh_fast(acc[e] + bias);
-        }
-        __syncthreads();
-        STAMP(3);
-        // ---- head (R x AP): each wave of a net takes 16 of the 32 rows as one 16x16 tile
-        {
-            const float* W = sW3 + net * AP * LD;
-            const float* Hin = sH2 + (net * R + cb * 16) * LD;
-            const f32x4 acc = mma16<H>([&](int i, int k) { return Hin[i * LD + k]; },
-                                       [&](int k, int j) { return W[j * LD + k]; });
-            const int col = lane & 15;
-            const float bias = sB3[net * AP + col];
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                sOut[(net * R + cb * 16 + 4 * (lane >> 4) + e) * LDO + col] = acc[e] + bias;
-        }
-        __syncthreads();
-        STAMP(4);
-        // ---- per-row Gaussian head + PPO terms (32 lanes), outputs overwritten by their gradients
-        if (tid < R) {
-            float* mu = sOut + (0 * R + tid) * LDO;
-            float* vv = sOut + (1 * R + tid) * LDO;
-            if (sSrc[tid] >= 0) {
-                const float4 rc = sRec[tid];
-                const float* act = sAct + tid * LDO;
-                float logp = 0.0f, ent = 0.0f;
-                if (a.continuous) {
-                    // Normal(mu, exp(logstd)): log-prob and entropy summed over action dims (actor_critic.py:36-43)
-                    for (int k = 0; k < A; ++k) {
-                        const float ls = sLs[k];
-                        const float zk = act[k] - mu[k];
-                        logp += (-(zk * zk) * (0.5f * sIvar[k]) - ls) - 0.9189385332046727f;
-                        ent += (0.5f + 0.9189385332046727f) + ls;
-                    }
-                    const PpoSample t = ppo_sample(logp, rc.x, rc.y, vv[0], rc.w, rc.z, mean, denom, invM, a.h);
-                    l_pg += t.pg; l_vl += t.vl; l_ent += ent; l_okl += t.okl; l_kl += t.kl; l_cf += t.cf;
-                    for (int k = 0; k < A; ++k) {
-                        const float zk = act[k] - mu[k];
-                        const float dmu = t.g_logp * (zk * sIvar[k]);
-                        mu[k] = dmu;
-                        sDls[tid * LDO + k] = t.g_logp * (zk * zk * sIvar[k] - 1.0f) + g_ent;
-                    }
-                    vv[0] = t.g_v;
-                    g_b3c += t.g_v;
-                } else {
-                    // Categorical(logits): log_softmax, log-prob of the stored action, entropy (actor_critic.py:45-50)
-                    float mx = mu[0];
-                    for (int k = 1; k < A; ++k) mx = fmaxf(mx, mu[k]);
-                    float se = 0.0f;
-                    for (int k = 0; k < A; ++k) se += expf(mu[k] - mx);
-                    const float lse = mx + logf(se);
-                    const int ai = (int)act[0];
-                    for (int k = 0; k < A; ++k) {
-                        const float lpk = mu[k] - lse;
-                        ent -= expf(lpk) * lpk;
-                        if (k == ai) logp = lpk;
-                    }
-                    const PpoSample t = ppo_sample(logp, rc.x, rc.y, vv[0], rc.w, rc.z, mean, denom, invM, a.h);
-                    l_pg += t.pg; l_vl += t.vl; l_ent += ent; l_okl += t.okl; l_kl += t.kl; l_cf += t.cf;
-                    // d logp / d z_k = [k == a] - p_k ;  d H / d z_k = -p_k (log p_k + H)
-                    for (int k = 0; k < A; ++k) {
-                        const float lpk = mu[k] - lse;
-                        const float pk = expf(lpk);
-                        mu[k] = t.g_logp * ((k == ai ? 1.0f : 0.0f) - pk) + g_ent * (-pk * (lpk + ent));
-                    }
-                    vv[0] = t.g_v;
-                    g_b3c += t.g_v;
-                }
-            } else {
-                for (int k = 0; k < AP; ++k) mu[k] = sDls[tid * LDO + k] = 0.0f;
-                vv[0] = 0.0f;
-            }
-        }
-        __syncthreads();
-        STAMP(5);
-        // ---- backward: dH2 -> dZ2, dW3
-        f32x16 dz2;
-        if (wave == 1 && lane < 2 * AP) {
-            // head-side column sums over the tile's rows: lanes 0..15 d b3 (actor), lanes 16..31 d logstd
-            const float* src = lane < AP ? sOut + lane : sDls + (lane - AP);
-            float cs = 0.0f;
-#pragma unroll
-            for (int r = 0; r < R; ++r) cs += src[r * LDO];
-            g_head += cs;
-        }
-        {
-            const float* dO = sOut + net * R * LDO;
-            const float* W3 = sW3 + net * AP * LD;
-            f32x16 acc = zero16();
-            mma32<AP>(acc, [&](int i, int k) { return dO[i * LDO + k]; },
-                  [&](int k, int j) { return W3[k * LD + cb * 32 + j]; });
-            const int col = cb * 32 + (lane & 31);
-            float colsum = 0.0f;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float h = sH2[(net * R + acc_row(e, lane)) * LD + col];
-                dz2[e] = acc[e] * (1.0f - h * h);
-                colsum += dz2[e];
-            }
-            colsum += __shfl_xor(colsum, 32, kWave);
-            gb2 += colsum;
-            // dW3 (rows < AP) x (in-block cb): A = dO^T, B = H2
-            const float* H2 = sH2 + net * R * LD;
-            mma32<R>(gW3, [&](int i, int k) { return i < AP ? dO[k * LDO + i] : 0.0f; },
-                  [&](int k, int j) { return H2[k * LD + cb * 32 + j]; });
-#pragma unroll
-            for (int e = 0; e < 16; ++e) sdZ[(net * R + acc_row(e, lane)) * LD + col] = dz2[e];
-        }
-        __syncthreads();
-        STAMP(6);
-        // ---- dW2 (two out-blocks x in-block cb), dH1 -> dZ1 (kept in registers until dZ2 is dead)
-        f32x16 dz1;
-        {
-            const float* dZ = sdZ + net * R * LD;
-            const float* H1 = sH1 + net * R * LD;
-#pragma unroll
-            for (int ob = 0; ob < 2; ++ob)
-                mma32<R>(gW2[ob], [&](int i, int k) { return dZ[k * LD + ob * 32 + i]; },
-                      [&](int k, int j) { return H1[k * LD + cb * 32 + j]; });
-            const float* W2 = sW2 + net * H * LD;
-            f32x16 acc = zero16();
-            mma32<H>(acc, [&](int i, int k) { return dZ[i * LD + k]; },
-                  [&](int k, int j) { return W2[k * LD + cb * 32 + j]; });
-            const int col = cb * 32 + (lane & 31);
-            float colsum = 0.0f;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float h = H1[acc_row(e, lane) * LD + col];
-                dz1[e] = acc[e] * (1.0f - h * h);
-                colsum += dz1[e];
-            }
-            colsum += __shfl_xor(colsum, 32, kWave);
-            gb1 += colsum;
-        }
-        __syncthreads();
-        STAMP(7);
-        {
-            const int col = cb * 32 + (lane & 31);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) sdZ[(net * R + acc_row(e, lane)) * LD + col] = dz1[e];
-        }
-        __syncthreads();
-        STAMP(8);
-        // ---- dW1 (two out-blocks x in-block cb of D)
-        if (cb * 32 < D) {
-            const float* dZ = sdZ + net * R * LD;
-#pragma unroll
-            for (int ob = 0; ob < 2; ++ob)
-                mma32<R>(gW1[ob], [&](int i, int k) { return dZ[k * LD + ob * 32 + i]; },
-                         [&](int k, int j) { return sX[k * LD + cb * 32 + j]; });
-        }
-        __syncthreads();
-        STAMP(9);
-    }
-
-    STAMP(10);
-    // ---- write this workgroup's gradient slab
-    float* slab = a.slabs + (size_t)blockIdx.x * a.L.n_params;
-    {
-        const int col = cb * 32 + (lane & 31);
-#pragma unroll
-        for (int ob = 0; ob < 2; ++ob) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int o = ob * 32 + acc_row(e, lane);
-                if (col < D) slab[a.L.w1[net] + o * D + col] = gW1[ob][e];
-                slab[a.L.w2[net] + o * H + col] = gW2[ob][e];
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int o = acc_row(e, lane);
-            if (o < out_dim[net]) slab[a.L.w3[net] + o * H + col] = gW3[e];
-        }
-        if (lane < 32) {
-            slab[a.L.b1[net] + col] = gb1;
-            slab[a.L.b2[net] + col] = gb2;
-        }
-    }
-    if (wave == 1) {
-        if (lane < A) slab[a.L.b3[0] + lane] = g_head;
-        if (a.continuous && lane >= AP && lane - AP < A) slab[a.L.logstd + lane - AP] = g_head;
-    }
-    if (wave == 0) {
-        float c = lane < R ? g_b3c : 0.0f;
-        double v6[6] = {l_pg, l_vl, l_ent, l_okl, l_kl, l_cf};
-#pragma unroll
-        for (int off = 16; off > 0; off >>= 1) c += __shfl_down(c, off, kWave);
-#pragma unroll
-        for (int q = 0; q < 6; ++q) {
-            double x = lane < R ? v6[q] : 0.0;
-#pragma unroll
-            for (int off = 16; off > 0; off >>= 1) x += __shfl_down(x, off, kWave);
-            v6[q] = x;
-        }
-        if (lane == 0) {
-            slab[a.L.b3[1]] = c;
-            double* lp = a.loss_part + (size_t)blockIdx.x * 8;
-#pragma unroll
-            for (int q = 0; q < 6; ++q) lp[q] = v6[q];
-            lp[6] = (double)mean;
-            lp[7] = (double)s_std;
-        }
-    }
-#ifdef AURPPO_MLP_STAMPS
-    STAMP(11);
-    if (tid == 0)
-        for (int k = 0; k < 16; ++k) a.stamps[(size_t)blockIdx.x * 16 + k] = st_acc[k];
-#endif
 }
 
 // ---- K8: forward-only sibling of K7 for the rollout step (src/ppo.py:103-108: policy.evaluate(next_obs) under
@@ -826,12 +408,6 @@ __global__ __launch_bounds__(kThreads) void k_adam_chain(float* __restrict__ p, 
     }
 }
 
-constexpr size_t lds_bytes() {
-    // every term before sRec is a multiple of 4 floats, so the float4 array is 16-B aligned
-    return sizeof(float) * (size_t)(R * LD + 3 * 2 * R * LD + 2 * 2 * H * LD + 2 * AP * LD + 2 * R * LDO + 4 * H + 2 * AP + 2 * AP +
-                                    2 * R * LDO + 4 * R + R + 2 * R);
-}
-
 }  // namespace
 
 extern "C" size_t aurppo_mlp_workspace_bytes(int n_params) {
@@ -924,60 +500,41 @@ static int mlp_step_impl(const float* obs, const float* actions, const float* re
     hipStream_t s = (hipStream_t)stream;
     const int sb = stat_blocks_for(M);
     a.n_stat_blocks = sb;
-    static int variant_cached = 0;
-    if (!variant_cached || aurppo_live_knobs()) {
-        const char* ve = getenv("AURPPO_MLP_VARIANT");
-        variant_cached = (ve && *ve == '1') ? 1 : 2;
-    }
-    const int variant = variant_cached;
+    const AurppoKnobs& knobs = aurppo_knobs();
+    const int variant = knobs.k7_variant == 3 ? 3 : 2;   // 2: k_mlp_step2 (f32 MFMA); 3: k_mlp_step3 (3 x bf16-split MFMA)
     a.w1op = wv.w1op;
     a.tile_counter = wv.tile_counter;
+    a.static_tiles = knobs.static_tiles ? 1 : 0;
     double* sq_part = wv.sq_part;
     if (!(chain && chain->chained)) {   // otherwise the previous chained call has prepared all of this
         hipLaunchKernelGGL(k_adv_stats_idx, dim3(sb), dim3(kThreads), 0, s, a.rec, a.rec_stride, idx, M,
-                           reinterpret_cast<double (*)[2]>(stats), params, a.L.w1[0], a.L.w1[1], D,
-                           (variant == 2 || chain) ? a.w1op : nullptr, a.tile_counter);
+                           reinterpret_cast<double (*)[2]>(stats), params, a.L.w1[0], a.L.w1[1], D, a.w1op, a.tile_counter);
         AURPPO_LAUNCH_CHECK("k_adv_stats_idx");
     }
     const int n_tiles = (M + R - 1) / R;
     // One persistent workgroup per CU, minus one CU per XCD (AURPPO_MLP_SPARE_CUS, default 8; workgroups are dealt
     // round-robin over the 8 XCDs): the single-workgroup shuffle kernels of the side stream then have a CU of
-    // their own.  The one-set kernel strides statically over the tiles and runs at the pace of its slowest
-    // workgroup: sharing a CU with the 16-wave k_fy_accept stretched 92 % of its launches (rocprof in-situ: mean
-    // 263 us with 0-2 spare CUs, 214 us with 8).  The two-set kernel hands tiles out dynamically, but it fills a
-    // CU's register file, so a workgroup whose CU is taken starts late; 8 spare CUs measured 3.86-3.93 ms per
-    // update against 4.09-4.10 ms with none.
-    static int cus_of[kMaxDevices] = {0}, spare_env = -1;
+    // their own.  The kernel hands tiles out dynamically, but it fills a CU's register file, so a workgroup whose CU
+    // is taken starts late; 8 spare CUs measured 3.86-3.93 ms per update against 4.09-4.10 ms with none.
+    static int cus_of[kMaxDevices] = {0};
     const int dslot = aurppo_device_slot();
     if (!cus_of[dslot]) {
         hipDeviceProp_t prop;
         AURPPO_HIP_TRY(hipGetDeviceProperties(&prop, dslot));
         cus_of[dslot] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : kMaxGrid;
-        const char* e = getenv("AURPPO_MLP_SPARE_CUS");
-        if (e && *e) spare_env = atoi(e);
     }
     const int cus = cus_of[dslot];
-    const int spare = spare_env >= 0 ? spare_env : 8;
-    // AURPPO_MLP_VARIANT: 2 (default) = two tile sets per workgroup (mlp2.hip), 1 = one tile set (k_mlp_step below)
+    const int spare = knobs.k7_spare_cus >= 0 ? knobs.k7_spare_cus : 8;
     int grid = cus - spare;
     if (grid > kMaxGrid) grid = kMaxGrid;
     if (grid < 1) grid = 1;
-    const int tiles_per_wg = variant == 2 ? 2 : 1;
-    if (grid > (n_tiles + tiles_per_wg - 1) / tiles_per_wg) grid = (n_tiles + tiles_per_wg - 1) / tiles_per_wg;
-    static bool attr_set[kMaxDevices] = {false};
-    if (!attr_set[dslot]) {
-        AURPPO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_step),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes()));
-        attr_set[dslot] = true;
-    }
+    if (grid > (n_tiles + 1) / 2) grid = (n_tiles + 1) / 2;     // two tile sets per workgroup
     if (ev_begin) AURPPO_HIP_TRY(hipEventRecord((hipEvent_t)ev_begin, s));
-    if (variant == 2) {
+    {
         const int rc = launch_mlp_step2(a, grid, s);
         if (rc != AURPPO_OK) return rc;
-    } else {
-        hipLaunchKernelGGL(k_mlp_step, dim3(grid), dim3(kThreads), lds_bytes(), s, a);
-        AURPPO_LAUNCH_CHECK("k_mlp_step");
     }
+    (void)variant;
     if (ev_end) AURPPO_HIP_TRY(hipEventRecord((hipEvent_t)ev_end, s));
     const int n_red = (n_params + 63) / 64;
     hipLaunchKernelGGL(k_mlp_reduce<1>, dim3(n_red), dim3(1024), 0, s, a.slabs, a.loss_part, grid, n_params, a.h, grads,

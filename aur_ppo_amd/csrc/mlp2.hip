@@ -169,7 +169,11 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
     // s + S) and the counter starts behind them, because consecutive grabs land in the first sets to arrive (64 tiles
     // on 64 sets took three rounds instead of one).  The grab is issued behind the weight loads.
     const int n_sets = 2 * gridDim.x, my_set = 2 * blockIdx.x + set;
-    const bool fixed_start = n_tiles < 4 * n_sets;
+    // Diagnostic (AURPPO_STATIC_TILES): no counter at all -- set s takes tiles s, s + S, s + 2S, ...  Every sum of the launch is
+    // then formed in a fixed order and two launches on the same inputs give bit-identical slabs, whatever else the chip is
+    // doing (tests/test_determinism.py); in-situ it costs what the static stride cost before the counter.
+    const bool stat = a.static_tiles != 0;
+    const bool fixed_start = !stat && n_tiles < 4 * n_sets;
     const int dyn_base = fixed_start ? 2 * n_sets : 0;   // tile = dyn_base + counter value
     int grab_raw = 0;
     // ---- stage the shared weights (once per launch).  Every global load of the prologue is issued before the first
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
             b3r = a.params[e < od ? b3 + e : b3];
         }
         if (tid < AP) lsr = a.params[(a.continuous && tid < A) ? a.L.logstd + tid : a.L.w2[0]];
-        if (tid == 0) grab_raw = (int)atomicAdd(tile_counter + zero_off, fixed_start ? 2u : 8u);
+        if (tid == 0 && !stat) grab_raw = (int)atomicAdd(tile_counter + zero_off, fixed_start ? 2u : 8u);
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
 #pragma unroll
@@ -232,10 +236,12 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
     __syncthreads();
     if (w == 0) {
         const int g = s_grab;
-        const int base = fixed_start ? my_set : g + 4 * set;
-        t1 = fixed_start ? my_set + n_sets : base + 1;
-        t2 = fixed_start ? dyn_base + g + set : base + 2;
-        if (fixed_start) {
+        const int base = (fixed_start || stat) ? my_set : g + 4 * set;
+        t1 = (fixed_start || stat) ? my_set + n_sets : base + 1;
+        t2 = stat ? my_set + 2 * n_sets : (fixed_start ? dyn_base + g + set : base + 2);
+        if (stat) {
+            t3_raw = my_set + 3 * n_sets;
+        } else if (fixed_start) {
             if (lane == 0) t3_raw = (int)atomicAdd(tile_counter + zero_off, 1u);   // consumed a tile later
         } else {
             t3_raw = base + 3;
@@ -489,7 +495,8 @@ __global__ __launch_bounds__(kThreads2, 1) void k_mlp_step2(const MlpArgs a) {
             if (w == 0) {
                 // the grab issued one tile ago is tile it+3: fetch its indices (landed in LDS at the next S), grab again
                 const int t3 = dyn_base + __builtin_amdgcn_readfirstlane(t3_raw);
-                if (ln == 0) t3_raw = (int)atomicAdd(tile_counter + zero_off, 1u);
+                if (stat) t3_raw = t3 + n_sets;
+                else if (ln == 0) t3_raw = (int)atomicAdd(tile_counter + zero_off, 1u);
                 // raw index now, validity applied when it is landed at the next S: touching the loaded value here
                 // would wait for it, and for the grab issued just above
                 const int m = t3 * R + (sl & (R - 1));

@@ -1,4 +1,4 @@
-// Shared pieces of the fused MLP kernels (K7 k_mlp_step / k_mlp_step2, K8 k_mlp_act): tile constants, the
+// Shared pieces of the fused MLP kernels (K7 k_mlp_step2 / k_mlp_step3, K8 k_mlp_act): tile constants, the
 // argument block, the fp32 MFMA micro-kernels and the tanh used by every variant.
 #pragma once
 #include "ppo_math.h"
@@ -43,6 +43,7 @@ struct MlpArgs {
     int n_stat_blocks;
     int D, A;
     int continuous;        // 1: Gaussian head (A action dims), 0: Categorical head (A logits, one action index)
+    int static_tiles;      // diagnostic (AURPPO_STATIC_TILES): set s takes tiles s, s + S, s + 2S, ... -- a fixed summation order
     MlpLayout L;
     PpoHyper h;
 };

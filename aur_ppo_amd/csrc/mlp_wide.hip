@@ -63,6 +63,7 @@ struct WideArgs {
     float* out_logp;
     float* out_value;
     int N, net_base, net_count;
+    int static_tiles;      // diagnostic (AURPPO_STATIC_TILES): workgroup p of P takes tiles p, p + P, ... -- a fixed summation order
 };
 
 // stats[b] = partial (sum, sum of squares) of the minibatch's advantages; wop = every hidden layer of both nets in
@@ -378,9 +379,15 @@ __global__ __launch_bounds__(256, DUAL ? 2 : 1) void k_mlpw_step(const WideArgs 
     // workgroup works on next; rows are fetched one tile ahead, indices two to three.
     __shared__ int s_tile[4];
     unsigned* const ctr = a.tile_counter + (DUAL ? 0 : net);
+    const bool stat = a.static_tiles != 0;
+    const int n_wg = DUAL ? (int)gridDim.x : (int)(gridDim.x >> 1);   // workgroups that share this net's tiles
     if (tid == 0) {       // four consecutive tiles to start with; later ones one at a time (ids only ever grow)
-        const int t0 = (int)atomicAdd(ctr, 4u);
-        s_tile[0] = t0; s_tile[1] = t0 + 1; s_tile[2] = t0 + 2; s_tile[3] = t0 + 3;
+        if (stat) {
+            s_tile[0] = pair; s_tile[1] = pair + n_wg; s_tile[2] = pair + 2 * n_wg; s_tile[3] = pair + 3 * n_wg;
+        } else {
+            const int t0 = (int)atomicAdd(ctr, 4u);
+            s_tile[0] = t0; s_tile[1] = t0 + 1; s_tile[2] = t0 + 2; s_tile[3] = t0 + 3;
+        }
     }
     __syncthreads();
     if (tid < R) {
@@ -424,7 +431,7 @@ __global__ __launch_bounds__(256, DUAL ? 2 : 1) void k_mlpw_step(const WideArgs 
         // the tile after the three already known: asked for here, where this wave has no loads queued behind the atomic
         // (returns are in order), stored in s_tile at the end of the tile
         int tile4 = 0;
-        if (tid == 0) tile4 = (int)atomicAdd(ctr, 1u);
+        if (tid == 0) tile4 = stat ? tile + 4 * n_wg : (int)atomicAdd(ctr, 1u);
 
         // ---- loss lanes (one per row): this net's half of the PPO terms; head outputs become their gradients
         if (lrow < R) {
@@ -698,7 +705,9 @@ struct WideWs {
     float* slabs;        // (kMaxSlabs, n_params)
     double* sq_part;     // (ceil(n_params / 64)) clip partial sums left by k_mlp_reduce
 };
-WideWs wide_ws(void* workspace, int n_params) {
+// slabs a launch can write: two both-net workgroups per CU for the narrow shapes (small n_params), one pair per two CUs otherwise
+int wide_slab_cap(int hidden, int D) { return (hidden <= 64 && D <= 64) ? kMaxSlabs : kMaxGrid / 2; }
+WideWs wide_ws(void* workspace, int n_params, int slab_cap) {
     WideWs v;
     char* p = reinterpret_cast<char*>(workspace);
     v.stats = reinterpret_cast<double*>(p);
@@ -706,7 +715,7 @@ WideWs wide_ws(void* workspace, int n_params) {
     v.wop = reinterpret_cast<float*>(v.loss_part + 8 * kMaxSlabs);
     v.tile_counter = reinterpret_cast<unsigned*>(v.wop + kOpFloats);
     v.slabs = reinterpret_cast<float*>(v.tile_counter + 16);
-    v.sq_part = reinterpret_cast<double*>(v.slabs + (((size_t)kMaxSlabs * (size_t)n_params + 15) / 16) * 16);
+    v.sq_part = reinterpret_cast<double*>(v.slabs + (((size_t)slab_cap * (size_t)n_params + 15) / 16) * 16);
     return v;
 }
 
@@ -747,10 +756,12 @@ int launch_wide(K kernel, bool* attr_done, int grid, size_t lds_bytes, hipStream
 
 }  // namespace
 
-extern "C" size_t aurppo_mlp_wide_workspace_bytes(int n_params) {
-    // slabs: two both-net workgroups per CU for the narrow shapes (their n_params is small), one pair per two CUs otherwise
+extern "C" size_t aurppo_mlp_wide_workspace_bytes(int n_params, int hidden, int state_dim) {
+    // the slab region is sized from the shape (512 slabs of a narrow policy's few parameters, 128 of a wide one's many: 52 MB
+    // instead of 207 MB at 3 x 128 over 128 state floats); n_params = 0: the operand copies alone, all K8w needs
+    const size_t slabs = (size_t)wide_slab_cap(hidden, state_dim) * (size_t)(n_params > 0 ? n_params : 0);
     return sizeof(double) * (2 * kStatBlocks + 8 * kMaxSlabs) + sizeof(float) * (size_t)kOpFloats + 64 +
-           sizeof(float) * (size_t)kMaxSlabs * (size_t)n_params + 64 + sizeof(double) * (size_t)((n_params + 63) / 64) + 64;
+           sizeof(float) * slabs + 64 + sizeof(double) * (size_t)((n_params + 63) / 64) + 64;
 }
 
 namespace {
@@ -786,7 +797,7 @@ static int wide_step_impl(const float* obs, const float* actions, const float* r
     rc = fill_layout(a.L, layout_h, num_layers, continuous, n_params, who);
     if (rc != AURPPO_OK) return rc;
     a.h = make_hyper(M, clip, ent_coef, vf_coef, norm_adv, vloss_mode);
-    const WideWs wv = wide_ws(workspace, n_params);
+    const WideWs wv = wide_ws(workspace, n_params, wide_slab_cap(hidden, D));
     a.stats = wv.stats; a.loss_part = wv.loss_part; a.wop = wv.wop; a.slabs = wv.slabs; a.tile_counter = wv.tile_counter;
     hipStream_t s = (hipStream_t)stream;
     int sb = (M + 1023) / 1024;
@@ -806,7 +817,10 @@ static int wide_step_impl(const float* obs, const float* actions, const float* r
     // layers and state at most two 32-column blocks wide: one workgroup carries both nets (k_mlpw_step<., true>)
     const bool dual = hidden <= 64 && D <= 64;
     // 8 CUs left to the side stream's shuffle kernels, as K7; a both-net workgroup is built to share its CU with a second one
-    int pairs = dual ? 2 * (cus_of[dslot] - 8) : (cus_of[dslot] - 8) / 2;
+    const AurppoKnobs& knobs = aurppo_knobs();
+    a.static_tiles = knobs.static_tiles ? 1 : 0;
+    const int spare = knobs.k7_spare_cus >= 0 ? knobs.k7_spare_cus : 8;
+    int pairs = dual ? 2 * (cus_of[dslot] - spare) : (cus_of[dslot] - spare) / 2;
     if (pairs > (dual ? kMaxSlabs : kMaxGrid / 2)) pairs = dual ? kMaxSlabs : kMaxGrid / 2;
     if (pairs > n_tiles) pairs = n_tiles;
     if (pairs < 1) pairs = 1;
@@ -877,7 +891,7 @@ extern "C" int aurppo_mlp_wide_act_f32(const float* obs, const float* noise, int
     a.net_count = noise ? 2 : 1;
     rc = fill_layout(a.L, layout_h, num_layers, continuous, n_params, who);
     if (rc != AURPPO_OK) return rc;
-    const WideWs wv = wide_ws(workspace, n_params);
+    const WideWs wv = wide_ws(workspace, 0, 0);      // the operand copies sit in front of the slabs
     a.wop = wv.wop;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(k_mlpw_prep, dim3(96), dim3(256), 0, s, params, a.L, num_layers, D, hidden, wv.wop,

@@ -608,8 +608,7 @@ static hipError_t own_cu_setup() {
 // Diagnostic knob AURPPO_K2_ONE_STREAM=1: the twist and the resolves run on the caller's stream too (everything serial) -- used
 // to tell how much of the main stream's slowdown comes from HOW MANY streams are busy rather than from what runs on them.
 static hipStream_t fill_stream_of(aurppo_rng* rng, hipStream_t s) {
-    static const bool one = [] { const char* e = getenv("AURPPO_K2_ONE_STREAM"); return e && *e == '1'; }();
-    return one ? s : rng->fill_stream;
+    return aurppo_knobs().k2_one_stream == 1 ? s : rng->fill_stream;
 }
 
 static int enqueue_fill(aurppo_rng* rng, double need, hipStream_t after, int slot, int cur_slot) {
@@ -670,11 +669,7 @@ int permute_once(aurppo_rng* rng, const int32_t* in, int32_t* out, int n, hipStr
     // file of every CU but the spare ones, so a few dozen workgroups are all that is ever resident; one workgroup per
     // 256 positions (2048 of them at B = 524 288) cost every K7 launch it overlapped 8-10 us (rocprof,
     // tools/k7_overlap.sh): 2.73 -> 2.68 ms per update with 48.  AURPPO_K2_LINK_WGS overrides (0 = one per 256).
-    static int link_wgs = -1;
-    if (link_wgs < 0) {
-        const char* e = getenv("AURPPO_K2_LINK_WGS");
-        link_wgs = e && *e ? atoi(e) : 48;
-    }
+    const int link_wgs = aurppo_knobs().k2_link_wgs;
     if (rng->use_post) AURPPO_HIP_TRY(hipStreamWaitEvent(ls, rng->ev_acc[slot], 0));
     hipLaunchKernelGGL(k_fy_link, dim3(link_wgs > 0 && link_wgs < grid ? link_wgs : grid), dim3(256), 0, ls, rng->d_j[slot],
                        rng->d_head[h], rng->d_next[slot], n, rng->d_head[hn], clr_n);
@@ -696,15 +691,11 @@ int permute_once(aurppo_rng* rng, const int32_t* in, int32_t* out, int n, hipStr
     }
     hipStream_t rs = rng->use_post ? rng->post_stream : fs;
     if (!rng->use_post) AURPPO_HIP_TRY(hipStreamWaitEvent(rs, rng->ev_link[slot], 0));
-    static int resolve_wgs = -1;
-    if (resolve_wgs < 0) {
-        const char* e = getenv("AURPPO_K2_RESOLVE_WGS");
-        // default 256 workgroups striding over the positions (0 = one per 256 positions, 2048 of them at B = 524 288).
-        // Round 1 had no slack on the shuffle streams to pay for a slower resolve; with 0.5 ms of it (round 2) a bounded
-        // grid is affordable: 64 / 128 / 192 / 256 / 512 workgroups -> main stream +17 % (shuffle-bound) / -1.2 % (slack 0)
-        // / -0.9 % (slack 0.17 ms) / -0.6 % (0.28 ms) / -0.6 % (0.37 ms), alternating runs on one box.
-        resolve_wgs = e && *e ? atoi(e) : 256;
-    }
+    // default 256 workgroups striding over the positions (0 = one per 256 positions, 2048 of them at B = 524 288).
+    // Round 1 had no slack on the shuffle streams to pay for a slower resolve; with 0.5 ms of it (round 2) a bounded
+    // grid is affordable: 64 / 128 / 192 / 256 / 512 workgroups -> main stream +17 % (shuffle-bound) / -1.2 % (slack 0)
+    // / -0.9 % (slack 0.17 ms) / -0.6 % (0.28 ms) / -0.6 % (0.37 ms), alternating runs on one box.
+    const int resolve_wgs = aurppo_knobs().k2_resolve_wgs;
     hipLaunchKernelGGL(k_fy_resolve, dim3(resolve_wgs > 0 && resolve_wgs < grid ? resolve_wgs : grid), dim3(256), 0, rs,
                        rng->d_j[slot], rng->d_head[h], rng->d_next[slot], in, out, n);
     AURPPO_LAUNCH_CHECK("k_fy_resolve");
@@ -764,8 +755,7 @@ extern "C" int aurppo_mt19937_create(aurppo_rng** out, uint32_t seed, int max_n,
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
         e = hipStreamCreateWithPriority(&r->fill_stream, hipStreamNonBlocking, hi);
         if (e == hipSuccess) e = hipStreamCreateWithPriority(&r->post_stream, hipStreamNonBlocking, hi);
-        const char* pe = getenv("AURPPO_K2_POST_STREAM");
-        r->use_post = (pe && *pe == '1') ? 1 : 0;
+        r->use_post = aurppo_knobs().k2_post_stream == 1 ? 1 : 0;
     }
     for (int k = 0; k < 2 && e == hipSuccess; ++k) {
         e = hipEventCreateWithFlags(&r->ev_fill[k], hipEventDisableTiming);

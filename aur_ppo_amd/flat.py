@@ -142,7 +142,13 @@ class FlatAdamMixin:
         """Weights + optimizer + ``trainer_state()`` in one ``.pt``.  ``robot_ppo`` keeps upstream's keys
         (``actor_state`` / ``critic_state`` / ``optimizer_state``, src/robot_ppo.py:502-507) and adds to them."""
         sd = {k: {n: v.detach().cpu().clone() for n, v in m.state_dict().items()} for k, m in self._checkpoint_nets()}
-        sd["optimizer_state"] = self.optimizer.state_dict()
+        osd = self.optimizer.state_dict()
+        # plain numbers in the param groups (the capturable optimizer keeps lr in a device tensor) and CPU state tensors:
+        # the file then holds nothing but tensors, numbers, strings, lists and dicts and loads with ``weights_only=True``
+        osd["param_groups"] = [{k: (float(v) if torch.is_tensor(v) else v) for k, v in g.items()} for g in osd["param_groups"]]
+        osd["state"] = {i: {k: (v.detach().cpu().clone() if torch.is_tensor(v) else v) for k, v in st.items()}
+                        for i, st in osd["state"].items()}
+        sd["optimizer_state"] = osd
         sd["trainer_state"] = self.trainer_state()
         sd["update"] = int(update)
         extra = getattr(self, "_checkpoint_extra", None)
@@ -151,8 +157,10 @@ class FlatAdamMixin:
         torch.save(sd, path)
 
     def load_checkpoint(self, path):
-        """Inverse of ``save_checkpoint``; returns the number of updates the saved run had completed."""
-        sd = torch.load(path, map_location="cpu", weights_only=False)
+        """Inverse of ``save_checkpoint``; returns the number of updates the saved run had completed.  Also accepts a
+        reference-format file (the weights and ``optimizer_state`` only, src/robot_ppo.py:502-507) and a checkpoint written
+        on the other optimizer path: Adam's moments are then taken from ``optimizer_state``."""
+        sd = torch.load(path, map_location="cpu", weights_only=True)
         with torch.no_grad():
             for k, m in self._checkpoint_nets():
                 tgt = m.state_dict()
@@ -161,8 +169,27 @@ class FlatAdamMixin:
             restore = getattr(self, "_checkpoint_restore", None)
             if restore is not None:
                 restore(sd)
+        ts = sd.get("trainer_state") or {}
+        osd = sd.get("optimizer_state")
         if not getattr(self, "_fused_adam", False):
-            self.optimizer.load_state_dict(sd["optimizer_state"])
-        self.load_trainer_state(sd["trainer_state"])
+            if osd is not None:
+                self.optimizer.load_state_dict(osd)
+        elif "adam_m" not in ts and osd is not None and osd.get("state"):
+            # saved by torch's per-parameter Adam (the CPU path, or upstream itself): re-home exp_avg / exp_avg_sq / step in the
+            # flat moment buffers K6b reads (state index = position in the param group = position in the bucket)
+            with torch.no_grad():
+                off, step = 0, 0.0
+                for i, p in enumerate(self.bucket.params):
+                    k = p.numel()
+                    st = osd["state"].get(i)
+                    if st is not None:
+                        self._adam_m[off:off + k].copy_(st["exp_avg"].reshape(-1))
+                        self._adam_v[off:off + k].copy_(st["exp_avg_sq"].reshape(-1))
+                        step = max(step, float(st["step"]))
+                    off += k
+                self._adam_t.fill_(step)
+        if "lr" not in ts:
+            ts = dict(ts, lr=(float(osd["param_groups"][0]["lr"]) if osd is not None else self.get_lr()))
+        self.load_trainer_state(ts)
         self.bucket.check_attached()
         return int(sd.get("update", 0))

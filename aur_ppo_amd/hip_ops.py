@@ -329,6 +329,11 @@ def mlp_layout(policy, bucket):
     return dict(offsets=seq, n_params=pos, D=D, A=A, continuous=cont, hidden=Hd, num_layers=NL, wide=not fast)
 
 
+def k7_variant():
+    """Which build of the fused MLP step the library launches for the default 64-64 policy (include/aurppo.h)."""
+    return int(_lib_or_raise().aurppo_k7_variant())
+
+
 def mlp_step_flops(layout, M):
     """Algorithmic FLOPs of one K7 / K7w launch (un-padded): forward of both nets, weight gradients of every
     layer, input gradients of every layer but the first (which needs none)."""
@@ -388,7 +393,7 @@ def mlp_ppo_step(obs, actions, rec, idx, flat_param, layout, flat_grad, clip, en
     if out_scalars is None:
         out_scalars = torch.empty(N_SCALARS, dtype=torch.float32, device=obs.device)
     if layout.get("wide"):
-        ws = _workspace("mlp_wide", lib.aurppo_mlp_wide_workspace_bytes(n), obs.device)
+        ws = _workspace("mlp_wide", lib.aurppo_mlp_wide_workspace_bytes(n, layout["hidden"], D), obs.device)
         lay = (C.c_int * len(layout["offsets"]))(*layout["offsets"])
         if events is not None:
             for ev in events:
@@ -432,7 +437,7 @@ def mlp_ppo_minibatch(obs, actions, rec, idx, flat_param, layout, flat_grad, cli
     # alignment padding past n_params is left alone: its gradient is never written, so clip and Adam are no-ops there
     if layout.get("wide"):
         # K7w: prepare + step + slab reduce + clip/Adam, four launches (no hand-over between calls: next_idx / chained unused)
-        ws = _workspace("mlp_wide", lib.aurppo_mlp_wide_workspace_bytes(n), obs.device)
+        ws = _workspace("mlp_wide", lib.aurppo_mlp_wide_workspace_bytes(n, layout["hidden"], D), obs.device)
         lay = (C.c_int * len(layout["offsets"]))(*layout["offsets"])
         _check(lib.aurppo_mlp_wide_ppo_minibatch_f32(
             _ptr(obs), _optr(actions), _ptr(rec), _ptr(idx, torch.int32), M, D, A, int(cont), layout["hidden"], layout["num_layers"],
@@ -513,7 +518,7 @@ def mlp_act(obs, noise, flat_param, layout, actions=None, logp=None, value=None)
         raise ValueError("mlp_act: obs / value shapes do not match the policy")
     null = C.c_void_p(0)
     if layout.get("wide"):
-        ws = _workspace("mlp_wide", lib.aurppo_mlp_wide_workspace_bytes(layout["n_params"]), dev)
+        ws = _workspace("mlp_wide", lib.aurppo_mlp_wide_workspace_bytes(0, layout["hidden"], layout["D"]), dev)
         lay = (C.c_int * len(layout["offsets"]))(*layout["offsets"])
         _check(lib.aurppo_mlp_wide_act_f32(_ptr(obs), _ptr(noise) if noise is not None else null, N, D, A, int(cont),
                                            layout["hidden"], layout["num_layers"], _ptr(flat_param), lay, layout["n_params"],

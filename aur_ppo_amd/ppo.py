@@ -159,6 +159,7 @@ class ppo(FlatAdamMixin):
         self._rec = None           # (B,4) per-sample record written by K1
         self._rec_of = None
         self._probe = None         # bench.py hangs HIP-event pairs around the gather launches here
+        self.first_grad_probe = None   # bench.py / tests: set to [] and the next update appends a copy of step 1's REDUCED gradient
 
     # ------------------------------------------------------------------ seeding / shuffle stream
     def seed_all(self, seed=1):
@@ -342,7 +343,8 @@ class ppo(FlatAdamMixin):
         packed = self._rec_of is not None and self._rec_of[0] is returns and self._rec_of[1] is advantages
         perms = self._take_perms()
         self._last_perms = perms        # complete and valid: what the probes below may index with
-        graphable = self.use_graph and packed and self.target_kl is None and self._probe is None
+        graphable = (self.use_graph and packed and self.target_kl is None and self._probe is None
+                     and self.first_grad_probe is None)
         if not graphable:
             return self._update_body(returns, advantages, perms, packed)
         if self._graph_state == 0:
@@ -408,6 +410,8 @@ class ppo(FlatAdamMixin):
                                      self.bucket.flat_grad, self.clip_coeff, self.entropy_coeff, self.value_coeff,
                                      self.norm_adv, vmode, self._scalars[step], self._adam_t, chained=step > 0)
                     D.allreduce_sum_(self.bucket.flat_grad, self.world, force=True)
+                    if step == 0 and self.first_grad_probe is not None:
+                        self.first_grad_probe.append(self.bucket.flat_grad.detach().clone() / self.world)
                     ops.mlp_ppo_apply(self.bucket.flat_param, self.bucket.flat_grad, self._adam_m, self._adam_v, self._mlp,
                                       self._lr_tensor, self._adam_t, self.max_grad_norm, g["betas"], g["eps"],
                                       self._norms[step:step + 1], grad_scale=1.0 / self.world, rec=k7_rec, next_idx=nxt)
@@ -427,6 +431,8 @@ class ppo(FlatAdamMixin):
                                      self.bucket.flat_grad, self.clip_coeff, self.entropy_coeff, self.value_coeff,
                                      self.norm_adv, vmode, self._scalars[step])
                     D.allreduce_mean_(self.bucket.flat_grad, self.world, force=self._dp)
+                    if step == 0 and self.first_grad_probe is not None:
+                        self.first_grad_probe.append(self.bucket.flat_grad.detach().clone())
                     self._clip_and_step(self._norms[step:step + 1])
                     step += 1
                     continue

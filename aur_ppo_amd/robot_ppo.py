@@ -369,7 +369,8 @@ class robot_ppo(FlatAdamMixin):
         writer.add_text("hyperparameters", "|param|value|\n|-|-|\n%s" % (
             "\n".join([f"|{key}|{str(self.params_dict[key])}|" for key in self.params_dict])))
         self.seed_all(1)
-        if self.do_pretraining:
+        resume = self.params_dict.get("resume")
+        if self.do_pretraining and not resume:      # a resumed run already holds the pre-trained (and further trained) weights
             self.policy.train()
             next_state, next_obs, next_done = self.pretrain()
             returns, advantages = self.advantages(next_state, next_obs, next_done, self.pretrain_buffer, self.pretrain_steps)
@@ -383,9 +384,13 @@ class robot_ppo(FlatAdamMixin):
         next_done = torch.zeros(self.num_envs, device=self.device)
         policy_losses = []
         first_update = 1
-        if self.params_dict.get("resume"):          # not upstream: continue an interrupted run (weights, Adam, RNG, update)
-            first_update = self.load_checkpoint(self.params_dict["resume"]) + 1
+        if resume:          # not upstream: continue an interrupted run (weights, Adam, RNG, update)
+            first_update = self.load_checkpoint(resume) + 1
             global_step = (first_update - 1) * self.batch_size * self.world
+            for u in range(1, first_update):         # the expert weight is a running product over the updates already done
+                if self.anneal_exp:
+                    self.expert_weight *= 1 - ((u - 1) / self.num_updates)
+        ck_path, ck_every = self.params_dict.get("checkpoint_path"), int(self.params_dict.get("checkpoint_every") or 0)
         for update in range(first_update, self.num_updates + 1):
             if self.anneal_lr:
                 frac = 1.0 - (update - 1.0) / self.num_updates
@@ -415,6 +420,8 @@ class robot_ppo(FlatAdamMixin):
             writer.add_scalar("losses/clipfrac", np.mean(clip_fracs), global_step)
             writer.add_scalar("losses/explained_variance", explained_var, global_step)
             writer.add_scalar("charts/SPS", int(global_step / (time.time() - start_time)), global_step)
+            if ck_path and ck_every > 0 and update % ck_every == 0 and self.rank == 0:
+                self.save_checkpoint(ck_path, update=update)      # mid-run: what --resume continues from
         self.envs.close()
         writer.close()
         if self.save_file_path is not None and self.rank == 0:

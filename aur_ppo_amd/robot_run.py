@@ -57,7 +57,9 @@ def build_parser():
     # extras (not upstream; defaults reproduce upstream): image shape of the Synthetic-arm workloads, resume file
     p.add_argument("--obs_size", type=int, default=128)
     p.add_argument("--obs_channels", type=int, default=1)
-    p.add_argument("--resume", type=str, default=None)
+    p.add_argument("--resume", type=str, default=None, help="continue from a checkpoint written by --checkpoint_path")
+    p.add_argument("--checkpoint_path", type=str, default=None, help="where to write mid-run checkpoints")
+    p.add_argument("--checkpoint_every", type=int, default=0, help="updates between mid-run checkpoints (0 = none)")
     return p
 
 
@@ -66,7 +68,7 @@ PARAM_KEYS = ("gym_id", "seed", "num_steps", "gae", "total_timesteps", "anneal_l
               "target_kl", "norm_adv", "capture_video", "hidden_dim", "continuous", "learning_rate", "exp_name",
               "num_layers", "dropout", "gamma", "track", "pretrain_episodes", "pretrain_steps", "pretrain_batch_size",
               "expert_weight", "equivariant", "anneal_exp", "save_file_path", "render", "do_pretraining",
-              "obs_size", "obs_channels", "resume")
+              "obs_size", "obs_channels", "resume", "checkpoint_path", "checkpoint_every")
 
 
 def params_from_args(args):

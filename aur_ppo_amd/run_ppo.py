@@ -57,6 +57,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--keep_hparams", action="store_true", help="do not apply the --continuous hyper-parameter override")
     p.add_argument("--obs_dim", type=int, default=None, help="Synthetic-v0 observation width")
     p.add_argument("--act_dim", type=int, default=None, help="Synthetic-v0 action width / count")
+    p.add_argument("--resume", type=str, default=None, help="continue from a checkpoint written by --checkpoint_path")
+    p.add_argument("--checkpoint_path", type=str, default=None, help="where to write mid-run checkpoints")
+    p.add_argument("--checkpoint_every", type=int, default=0, help="updates between mid-run checkpoints (0 = none)")
     return p
 
 
@@ -74,9 +77,11 @@ def params_from_args(args) -> dict:
             "target_kl", "norm_adv", "capture_video", "hidden_dim", "continuous", "learning_rate", "exp_name",
             "num_layers", "dropout", "gamma", "track")       # the params dict of src/run_ppo.py:53-81
     params = {k: getattr(args, k) for k in keys}
-    for k in ("obs_dim", "act_dim"):
+    for k in ("obs_dim", "act_dim", "resume", "checkpoint_path"):
         if getattr(args, k) is not None:
             params[k] = getattr(args, k)
+    if args.checkpoint_every:
+        params["checkpoint_every"] = args.checkpoint_every
     return params
 
 

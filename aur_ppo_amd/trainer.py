@@ -167,10 +167,13 @@ class ppoBulletTrainer(bulletTrainer):
 
     def step_env(self, s, o, global_step):
         """One env step for all processes (ppoBulletTrainer.py:67-103): act, ask the planner for the expert action, step,
-        record the nine transition fields as one dense row."""
+        record the nine transition fields as one dense row.  A finished episode is reset before the next ``act``: upstream
+        calls ``envs.reset_envs(done_idxes)`` and patches the returned state / observation rows (:78-85; it writes the reset
+        STATES into the observation rows, a slip -- the reset observations are meant); the wrapper's ``auto_reset=True`` does
+        that reset inside ``step`` and returns the patched rows, as ``robot_ppo.rewards_to_go`` uses it."""
         (u_a, a), lp, _m, v = self.agent.act(s.to(self.device), o.to(self.device))
         u_e, _e = self.agent.getActionFromPlan(self.envs.getNextAction())
-        n_s, n_o, r, d, dist = self._step(self.envs, a.to(self.device))
+        n_s, n_o, r, d, dist = self._step(self.envs, a.to(self.device), auto_reset=True)
         if self.replay_buffer is None:
             self.replay_buffer = DenseTransitionBuffer(self.num_env_steps, self.num_processes, tuple(o.shape[1:]),
                                                        u_a.shape[1], self.device)
@@ -235,10 +238,14 @@ class ppoBulletTrainer(bulletTrainer):
                 n_s, n_o, n_d, dist = self.step_env(n_s, n_o, self.global_step)
                 if dist is not None:
                     dists.append(torch.as_tensor(dist, device=self.device).reshape(-1))
+                if (_step + 1) % 2000 == 0:           # upstream's in-rollout evaluation (ppoBulletTrainer.py:166-168)
+                    self.evaluate(_step + 1)
             batch = self.replay_buffer.sample(self.ppo_batch)
             n_o_feed = self.agent._tile(n_o.to(self.device), n_s.to(self.device))
             self.agent.update(batch, n_o_feed, n_d.to(self.device), torch.cat(dists) if dists else None)
             self.replay_buffer.reset()
+            if self.global_step % 1000 == 0:          # ppoBulletTrainer.py:177-178
+                self.evaluate(self.global_step)
             self.writer.add_scalar("charts/SPS", int(self.global_step / max(time.time() - start, 1e-9)), self.global_step)
         self.envs.close()
         self.writer.close()

@@ -54,6 +54,9 @@ def parse():
     ap.add_argument("--no-probe", action="store_true", help="do not time the gather kernel with HIP events")
     ap.add_argument("--no-graph", action="store_true", help="run the update eagerly instead of as a hipGraph")
     ap.add_argument("--no-fused-mlp", action="store_true", help="per-op path (K3 + torch nets + K5) instead of K7")
+    ap.add_argument("--shard-envs-per-gpu", type=int, default=512, help="second workload measured in the same process: BASELINE "
+                    "config 4's per-GPU shard (0 = skip)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle comparison of the first (untimed) step")
     ap.add_argument("--force-dp", action="store_true", help="one rank, but the multi-GPU launch path: K7 grad -> RCCL "
                     "all-reduce (group of one) -> apply; rehearses the captured collective on a one-GPU box")
     return ap.parse_args()
@@ -206,19 +209,81 @@ def check_parity(gpu, res, net):
         g, r = gpu["scalars"][:, cols], res["scalars"][:, cols]
         out["scalars_max_excess"] = float((np.abs(g - r) - (1e-5 + 1e-4 * np.abs(r))).max())     # <= 0 passes
         out["clipfrac_max_abs_err"] = float(np.abs(gpu["scalars"][:, 6] - res["scalars"][:, 6]).max())
+        # Final weights after the 16 clip + Adam steps.  K7 / K7w hand row tiles to workgroups through a counter, so a
+        # gradient element's last bits depend on the launch (two launches on the same inputs: 1.4-7.5e-9 absolute,
+        # profiles/r02/grad_repeat_3x64.txt; with AURPPO_STATIC_TILES they are bit-identical, tests/test_determinism.py --
+        # summation order, not a race).  A weight whose gradient is far below Adam's eps moves by lr * m / eps per step, a
+        # gain of lr / eps = 30 on that difference, and from the second step on the differing weights feed back into the
+        # gradients, so the spread grows over the 16 steps instead of adding up linearly (16 x 30 x 7.5e-9 = 3.6e-6 would be
+        # the linear figure; observed between two correct runs: <= 3e-8 with K7, up to 9.4e-6 with K7w's both-net workgroups,
+        # profiles/r02/repeat_*.txt).  Gate: 2e-6 absolute for K7 (what its repeatability supports, and the K7 tests hold),
+        # 2e-5 for the K7w shapes; with static tiles K7w is held to 2e-6 too (tests/test_parity_fullsize.py).
+        w_atol = 2e-5 if gpu.get("wide") else 2e-6
         w_ex = []
         for k, v in net.state_dict().items():
             a, b = gpu["weights"][k], v.numpy()
-            # 2e-5 absolute: K7 / K7w hand tiles out through a counter, so a gradient element's last bits depend on the
-            # launch (measured 3e-7 of the tensor's max, tools/grad_repeatability.py; max |g| ~ 0.1 here), and Adam's step has
-            # sensitivity lr / eps = 30 to an element far below eps: 16 steps x 3e-4 x 4e-8 / 1e-5 = 1.9e-5 is how far two
-            # correct runs can end apart in such a weight (observed: 9e-6, tools/update_repeatability.py)
-            w_ex.append(float((np.abs(a - b) - (2e-5 + 1e-4 * np.abs(b))).max()))
+            w_ex.append(float((np.abs(a - b) - (w_atol + 1e-4 * np.abs(b))).max()))
         out["weights_max_excess"] = max(w_ex)
+        out["weights_atol"] = w_atol
         M = gpu["minibatch"]
         out["ok"] = bool(out["perms_bit_exact"] and out["adv_max_abs_err"] <= 1e-5 and out["ret_max_abs_err"] <= 1e-5
                          and gpu["scalars"].shape == res["scalars"].shape and out["scalars_max_excess"] <= 0
                          and out["clipfrac_max_abs_err"] <= 1.5 / M and out["weights_max_excess"] <= 0)
+    except Exception as e:
+        out["ok"] = False
+        out["error"] = f"{type(e).__name__}: {e}"
+    return out
+
+
+def check_parity_sharded(args, hp, N, world, init_sd, gpu, own_log_probs):
+    """SURVEY 8e's per-shard parity, run on rank 0 when W > 1: its advantages / returns / permutations and the loss scalars
+    of optimizer step 1 against ``oracle.reference_update`` on ITS shard, and the gradient the all-reduce delivered for step 1
+    against the mean of the per-shard oracle gradients (every shard's synthetic rollout is regenerated here from its seed,
+    1234 + rank; step 1 is the step all of whose inputs are known without running the other ranks' trajectories)."""
+    from oracle import ppo_oracle as O
+    out = {"ranks": world}
+    try:
+        T, Dm, A = args.num_steps, args.obs_dim, args.act_dim
+        hp1 = dict(hp)
+        grads, first = [], None
+        for r in range(world):
+            data = synth_buffers(T, N, Dm, A, 1234 + r)
+            net = O.make_actor_critic(Dm, (A,), args.hidden_dim, args.num_layers, True)
+            net.load_state_dict(init_sd)
+            if r == 0:
+                data["log_probs"] = own_log_probs
+            else:
+                with torch.no_grad():
+                    _, lp, _, _ = net.evaluate(data["states"].view(-1, Dm), data["actions"].view(-1, A))
+                data["log_probs"] = lp.view(T, N)
+            buf = {k: data[k] for k in ("states", "actions", "log_probs", "rewards", "terminals", "values")}
+            opt = torch.optim.SGD(net.parameters(), lr=0.0)      # step 1 only: the optimizer never matters
+            g = []
+            res = O.reference_update(net, opt, buf, data["next_obs"], data["next_done"], hp1, np.random.RandomState(1),
+                                     collect=True, stop_after=1, grads_out=g)
+            grads.append(g[0].numpy().astype(np.float64))
+            if r == 0:
+                first = res
+        ref_g = np.mean(grads, axis=0)
+        B = T * N
+        perm = np.arange(B)
+        rs = np.random.RandomState(1)
+        perms_ok = True
+        for e in range(args.epochs):
+            rs.shuffle(perm)
+            perms_ok = perms_ok and bool(np.array_equal(gpu["perms"][e], perm))
+        out["perms_bit_exact"] = perms_ok
+        out["adv_max_abs_err"] = float(np.abs(gpu["adv"] - first["advantages"].numpy()).max())
+        out["ret_max_abs_err"] = float(np.abs(gpu["ret"] - first["returns"].numpy()).max())
+        cols = [0, 1, 2, 3, 4, 5, 7, 8]
+        g0, r0 = gpu["scalars"][0, cols], first["scalars"][0, cols]
+        out["step1_scalars_max_excess"] = float((np.abs(g0 - r0) - (1e-5 + 1e-4 * np.abs(r0))).max())
+        got_g = gpu["first_grad"][:ref_g.size].astype(np.float64)
+        out["step1_reduced_grad_max_abs_err"] = float(np.abs(got_g - ref_g).max())
+        out["step1_reduced_grad_scale"] = float(np.abs(ref_g).max())
+        out["ok"] = bool(perms_ok and out["adv_max_abs_err"] <= 1e-5 and out["ret_max_abs_err"] <= 1e-5
+                         and out["step1_scalars_max_excess"] <= 0
+                         and out["step1_reduced_grad_max_abs_err"] <= 2e-5 * out["step1_reduced_grad_scale"] + 1e-8)
     except Exception as e:
         out["ok"] = False
         out["error"] = f"{type(e).__name__}: {e}"
@@ -259,6 +324,112 @@ def self_launch(args):
     sys.exit(rc)
 
 
+def run_workload(args, rank, world, dev, envs_per_gpu, steps, warmup, with_probe):
+    """One workload through the product path: build the trainer with ``envs_per_gpu`` envs on this rank, load the SURVEY 8d
+    synthetic rollout (seed 1234 + rank), run the untimed parity step, ``warmup`` steps, then EXACTLY ``steps`` timed steps
+    between barrier + synchronize pairs; max over ranks.  Returns everything the JSON line is built from."""
+    from aur_ppo_amd import dist as D
+    from aur_ppo_amd.ppo import ppo
+    torch.manual_seed(1)
+    a2 = argparse.Namespace(**vars(args))
+    a2.envs_per_gpu = envs_per_gpu
+    hp = hyper(a2, world)
+    hp["device"] = dev
+    hp["fused_mlp"] = not args.no_fused_mlp
+    hp["force_dp"] = args.force_dp
+    agent = ppo(hp)
+    T, N, Dm, A = args.num_steps, agent.num_envs, args.obs_dim, args.act_dim
+    data = synth_buffers(T, N, Dm, A, 1234 + rank)
+    init_sd = {k: v.detach().cpu().clone() for k, v in agent.policy.state_dict().items()}
+    for k in ("states", "actions", "values", "rewards", "terminals"):
+        getattr(agent.buffer, k).copy_(data[k])
+    next_obs, next_done = data["next_obs"].to(dev), data["next_done"].to(dev)
+    with torch.no_grad():   # old log-probs = the policy's own, at init weights (ratio ~ 1 at epoch 0)
+        _, lp, _, _ = agent.policy.evaluate(agent.buffer.states.view(-1, Dm), agent.buffer.actions.view(-1, A))
+        agent.buffer.log_probs.copy_(lp.view(T, N))
+    data["log_probs"] = agent.buffer.log_probs.cpu()
+    agent.seed_all(1)
+    probe = EventProbe()
+    if args.no_graph:
+        agent.use_graph = False
+    step_no = [0]
+    mlp_events = []
+    every = 5 if steps < 50 else 10          # the stand-alone probe launch: every 5th step of a short run, every 10th otherwise
+
+    def one_step():
+        returns, advantages = agent.advantages(next_obs, next_done)
+        agent.update(returns, advantages)
+        step_no[0] += 1
+        if with_probe and probe.on and not args.no_probe and step_no[0] % every == 1:
+            # The update replays as a hipGraph, whose kernels cannot carry readable events: every `every`-th
+            # step, time ONE extra stand-alone launch of the dominant kernel on the update's own inputs
+            # (it sits inside the timed region: 150 us per ten 2.7 ms steps).
+            if agent._mlp is not None:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                agent.probe_mlp_step(ev)       # events recorded inside the library, around the step kernel only
+                mlp_events.append(ev)
+            else:
+                agent.probe_gather(probe)
+
+    log(f"rank {rank}/{world}: {envs_per_gpu} envs/GPU: setup done; parity step, then {warmup} warm-up steps")
+    # step 0 (untimed, eager): the update the oracle's first CPU update is compared with
+    dp = world > 1 or args.force_dp
+    if dp:
+        agent.first_grad_probe = []
+    returns, advantages = agent.advantages(next_obs, next_done)
+    n0 = agent.update(returns, advantages)
+    torch.cuda.synchronize()
+    first_grad = agent.first_grad_probe[0].cpu().numpy() if (dp and agent.first_grad_probe) else None
+    agent.first_grad_probe = None
+    gpu_first = None
+    if rank == 0:
+        gpu_first = dict(adv=advantages.cpu().numpy(), ret=returns.cpu().numpy(), perms=agent._last_perms.cpu().numpy(),
+                         scalars=agent._scalars[:n0].cpu().numpy().astype(np.float64), minibatch=agent.minibatch_size,
+                         wide=bool(agent._mlp is not None and agent._mlp.get("wide")), first_grad=first_grad,
+                         weights={k: v.detach().cpu().numpy().copy() for k, v in agent.policy.state_dict().items()})
+    for _ in range(warmup):
+        one_step()
+    torch.cuda.synchronize()
+    log(f"{envs_per_gpu} envs/GPU: warm-up done, timing {steps} steps")
+    probe.on = True
+    side = []
+    agent._perm_events = [] if agent._perm_stream is not None else None
+    D.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_step()
+        if agent._perm_events is not None:          # when did the main stream finish this update?
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            side.append(e)
+    torch.cuda.synchronize()
+    D.barrier()
+    dt = time.perf_counter() - t0
+    probe.on = False
+    perm_events, agent._perm_events = agent._perm_events, None
+    log(f"{envs_per_gpu} envs/GPU: timed region {dt:.3f} s for {steps} steps")
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t)
+    sc = agent._scalars.cpu().numpy()
+    assert np.isfinite(sc).all(), "non-finite loss scalars in the timed region"
+    return dict(agent=agent, hp=hp, N=N, dt=dt, data=data, init_sd=init_sd, gpu_first=gpu_first, probe=probe,
+                mlp_events=mlp_events, side=side, perm_events=perm_events, every=every)
+
+
+def oracle_full_update(args, hp, N, data, init_sd):
+    """oracle.reference_update of one whole update on ``data`` from ``init_sd`` (the checker; CPU)."""
+    from oracle import ppo_oracle as O
+    net = O.make_actor_critic(args.obs_dim, (args.act_dim,), args.hidden_dim, args.num_layers, True)
+    net.load_state_dict(init_sd)
+    opt = torch.optim.Adam(net.parameters(), lr=hp["learning_rate"], eps=1e-5)
+    buf = {k: data[k] for k in ("states", "actions", "log_probs", "rewards", "terminals", "values")}
+    res = O.reference_update(net, opt, buf, data["next_obs"], data["next_done"], hp, np.random.RandomState(1), collect=True)
+    return res, net
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -282,87 +453,18 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    from aur_ppo_amd.ppo import ppo
-    torch.manual_seed(1)
-    hp = hyper(args, world)
-    hp["device"] = dev
-    hp["fused_mlp"] = not args.no_fused_mlp
-    hp["force_dp"] = args.force_dp
-    agent = ppo(hp)
-    T, N, Dm, A = args.num_steps, agent.num_envs, args.obs_dim, args.act_dim
-    data = synth_buffers(T, N, Dm, A, 1234 + rank)
-    init_sd = {k: v.detach().cpu().clone() for k, v in agent.policy.state_dict().items()}
-    for k in ("states", "actions", "values", "rewards", "terminals"):
-        getattr(agent.buffer, k).copy_(data[k])
-    next_obs, next_done = data["next_obs"].to(dev), data["next_done"].to(dev)
-    with torch.no_grad():   # old log-probs = the policy's own, at init weights (ratio ~ 1 at epoch 0)
-        _, lp, _, _ = agent.policy.evaluate(agent.buffer.states.view(-1, Dm), agent.buffer.actions.view(-1, A))
-        agent.buffer.log_probs.copy_(lp.view(T, N))
-    data["log_probs"] = agent.buffer.log_probs.cpu()
-    agent.seed_all(1)
-    probe = EventProbe()
-    if args.no_graph:
-        agent.use_graph = False
-
-    step_no = [0]
-    mlp_events = []
-
-    def one_step():
-        returns, advantages = agent.advantages(next_obs, next_done)
-        agent.update(returns, advantages)
-        step_no[0] += 1
-        if probe.on and not args.no_probe and step_no[0] % 10 == 1:
-            # The update replays as a hipGraph, whose kernels cannot carry readable events: every 10th
-            # step, time ONE extra stand-alone launch of the dominant kernel on the update's own inputs
-            # (it sits inside the timed region: 150 us per ten 2.7 ms steps).
-            if agent._mlp is not None:
-                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                agent.probe_mlp_step(ev)       # events recorded inside the library, around k_mlp_step only
-                mlp_events.append(ev)
-            else:
-                agent.probe_gather(probe)
-
-    log(f"rank {rank}/{world}: setup done; parity step, then {args.warmup} warm-up steps")
-    # step 0 (untimed, eager): the update the oracle's first CPU update is compared with
-    returns, advantages = agent.advantages(next_obs, next_done)
-    n0 = agent.update(returns, advantages)
-    torch.cuda.synchronize()
-    gpu_first = None
-    if rank == 0 and world == 1 and not args.force_dp:
-        gpu_first = dict(adv=advantages.cpu().numpy(), ret=returns.cpu().numpy(), perms=agent._last_perms.cpu().numpy(),
-                         scalars=agent._scalars[:n0].cpu().numpy().astype(np.float64), minibatch=agent.minibatch_size,
-                         weights={k: v.detach().cpu().numpy().copy() for k, v in agent.policy.state_dict().items()})
-    for _ in range(args.warmup):
-        one_step()
-    torch.cuda.synchronize()
-    log("warm-up done, timing")
-    probe.on = True
-    side = []
-    agent._perm_events = [] if agent._perm_stream is not None else None
-    D.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-        if agent._perm_events is not None:          # when did the main stream finish this update?
-            e = torch.cuda.Event(enable_timing=True)
-            e.record()
-            side.append(e)
-    torch.cuda.synchronize()
-    D.barrier()
-    dt = time.perf_counter() - t0
-    probe.on = False
-    perm_events, agent._perm_events = agent._perm_events, None
-    log(f"timed region: {dt:.3f} s for {args.steps} steps")
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t)
-    sc = agent._scalars.cpu().numpy()
-    assert np.isfinite(sc).all(), "non-finite loss scalars in the timed region"
+    run = run_workload(args, rank, world, dev, args.envs_per_gpu, args.steps, args.warmup, True)
+    # BASELINE config 4 / SURVEY 8e define the scaling curve at 512 envs per GPU: the same step at that shard size, in this
+    # same process (every N, so the driver can form the ratio from its N = 1 line)
+    shard = None
+    if args.shard_envs_per_gpu > 0 and args.shard_envs_per_gpu != args.envs_per_gpu:
+        shard = run_workload(args, rank, world, dev, args.shard_envs_per_gpu, args.steps, args.warmup, False)
     if rank != 0:
         D.shutdown()
         return
+    agent, dt, N = run["agent"], run["dt"], run["N"]
+    T, Dm, A = args.num_steps, args.obs_dim, args.act_dim
+    probe, mlp_events, side, perm_events = run["probe"], run["mlp_events"], run["side"], run["perm_events"]
     env_steps = world * N * T * args.steps
     M = agent.minibatch_size
 
@@ -399,24 +501,28 @@ def main():
                        "main_period_ms": round(ms_step, 4),
                        "how": "HIP events on the shuffle side stream (start/end of each update's E shuffles) and on the main "
                               "stream (end of each update) in this same timed region; medians"}
+    from aur_ppo_amd import hip_ops as H
+    k7_variant = H.k7_variant() if hasattr(H, "k7_variant") else 2
     roofline = None
     if mlp_events:
-        from aur_ppo_amd import hip_ops as H
         ms = float(np.mean([b.elapsed_time(e) for b, e in mlp_events]))
         flops = H.mlp_step_flops(agent._mlp, M)
         ach = flops / (ms * 1e-3) / 1e12
-        kname = ("k_mlpw_step (K7w" if agent._mlp.get("wide") else
-                 ("k_mlp_step" if os.environ.get("AURPPO_MLP_VARIANT") == "1" else "k_mlp_step2") + " (K7")
+        kname = ("k_mlpw_step (K7w" if agent._mlp.get("wide") else ("k_mlp_step3" if k7_variant == 3 else "k_mlp_step2") + " (K7")
         roofline = {"bound": "mfma", "kernel": kname + ": gather + actor/critic forward + PPO loss + backward)",
                     "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
                     "traffic": (pmc("mlp_wide_pmc.json", f"{args.num_layers}x{args.hidden_dim}") if agent._mlp.get("wide")
-                                else pmc("mlp_pmc.json")),
+                                else pmc("mlp3_pmc.json" if k7_variant == 3 else "mlp_pmc.json")),
                     "flops_per_launch": flops, "avg_launch_us": round(ms * 1e3, 2), "launches_timed": len(mlp_events),
                     "algorithmic_hbm_bytes_per_launch": M * (4 * (Dm + A + 4) + 4),
-                    "how": "hipEvent pair recorded inside the library around the K7 kernel, one extra stand-alone "
-                           "launch every 10th step on the update's own minibatch"
+                    "how": f"hipEvent pair recorded inside the library around the K7 kernel, one extra stand-alone "
+                           f"launch every {run['every']}th step on the update's own minibatch"
                            + (" (the update itself is a hipGraph)" if agent._graph is not None else "")}
+        if k7_variant == 3 and not agent._mlp.get("wide"):
+            roofline["arithmetic"] = ("fp32 operands as three bf16 planes each, six v_mfma_f32_32x32x16_bf16 products per "
+                                      "K = 16 (dropped terms <= 2^-24 relative), fp32 accumulate; `peak` stays the fp32 MFMA "
+                                      "peak the same FLOPs would be priced at on v_mfma_f32_32x32x2_f32")
     elif probe.pairs:
         gather_bytes = M * (8 * Dm + 8 * A + 36)          # idx + 6 streams read + written
         g_ms = probe.mean_ms()
@@ -425,40 +531,72 @@ def main():
                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc("gather_pmc.json"),
                     "bytes_per_launch": gather_bytes, "avg_launch_us": round(g_ms * 1e3, 2),
                     "launches_timed": len(probe.pairs),
-                    "how": "HIP-event pairs around one stand-alone launch every 10th step of the update's own gather"}
+                    "how": f"HIP-event pairs around one stand-alone launch every {run['every']}th step of the update's own gather"}
     if roofline is not None:
         roofline["hbm_8d"] = hbm_8d
         roofline["side_stream"] = side_stream
-    launch = "hipGraph" if agent._graph is not None else "eager"
-    if agent.graph_fallback:
-        launch += f" (capture failed: {agent.graph_fallback[:120]})"
-    elif agent._graph is None and world > 1 and not D.collectives_capturable():
-        launch += " (gloo rehearsal: a host-staged collective cannot be captured; RCCL runs captured)"
+
+    def launch_of(ag):
+        launch = "hipGraph" if ag._graph is not None else "eager"
+        if ag.graph_fallback:
+            launch += f" (capture failed: {ag.graph_fallback[:120]})"
+        elif ag._graph is None and world > 1 and not D.collectives_capturable():
+            launch += " (gloo rehearsal: a host-staged collective cannot be captured; RCCL runs captured)"
+        return launch
+
+    dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
+    fused = agent._mlp is not None and not agent._mlp.get("wide")
     out = {"metric": "env-steps/sec through GAE+PPO-update at num_envs=4096,T=128; 1/2/4/8 GPU",
            "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "vs_baseline": None,
+           "dtype": "f32 (3xbf16-split MFMA, fp32 accumulate)" if (fused and k7_variant == 3) else "f32", "data": "synthetic",
            "config": {"workload": f"synthetic continuous obs_dim={Dm} act_dim={A}, num_envs={N}/GPU x {world} GPU, "
                                   f"T={T}, E={args.epochs}, {args.minibatches} minibatches/epoch (M={M}), "
                                   f"{args.num_layers}x{args.hidden_dim} tanh MLP actor+critic, Adam, random-init weights",
                       "global_num_envs": N * world, "num_steps": T,
                       "parallelism": f"env-shard dp{world}" + (" (one rank through the RCCL launch path)" if args.force_dp else ""),
-                      "update_launch": launch,
+                      "rccl_ranks": torch.distributed.get_world_size() if dist_on else 1,
+                      "collective_backend": (torch.distributed.get_backend() if dist_on else None),
+                      "update_launch": launch_of(agent),
                       "minibatch_step": ("K3 + torch nets + K5" if agent._mlp is None else
-                                         "K7w fused MLP step + K6b" if agent._mlp.get("wide") else "K7 fused MLP step")},
+                                         "K7w fused MLP step + K6b" if agent._mlp.get("wide") else
+                                         f"K7 fused MLP step (variant {k7_variant})")},
            "roofline": roofline}
     parity = None
-    if world == 1 and args.cpu_baseline_updates > 0:
-        out["cpu_baseline"], parity = cpu_baseline(args, data, init_sd, args.cpu_baseline_updates, gpu_first)
+    if world == 1 and not args.force_dp and args.cpu_baseline_updates > 0:
+        out["cpu_baseline"], parity = cpu_baseline(args, run["data"], run["init_sd"], args.cpu_baseline_updates, run["gpu_first"])
     else:
         out["cpu_baseline"] = None
+        if (world > 1 or args.force_dp) and not args.no_parity:
+            parity = check_parity_sharded(args, run["hp"], N, world, run["init_sd"], run["gpu_first"], run["data"]["log_probs"])
     out["parity_checked"] = bool(parity["ok"]) if parity is not None else False
-    out["parity"] = parity if parity is not None else "not run (needs the N=1 cpu_baseline leg)"
+    out["parity"] = parity if parity is not None else "not run (--cpu-baseline-updates 0 / --no-parity)"
+    shard_ok = True
+    if shard is not None:
+        sa, sN = shard["agent"], shard["N"]
+        sp = None
+        if not args.no_parity:
+            if world == 1 and not args.force_dp:
+                res, net = oracle_full_update(args, shard["hp"], sN, shard["data"], shard["init_sd"])
+                sp = check_parity(shard["gpu_first"], res, net)
+            else:
+                sp = check_parity_sharded(args, shard["hp"], sN, world, shard["init_sd"], shard["gpu_first"],
+                                          shard["data"]["log_probs"])
+            shard_ok = bool(sp["ok"])
+        out["config4_shard"] = {"what": "BASELINE config 4 / SURVEY 8e: the same step at 512 envs per GPU (the shard the 8-GPU "
+                                        "metric is defined on), measured in this process right after the main workload",
+                                "envs_per_gpu": sN, "n_gpus": world, "value": world * sN * T * args.steps / shard["dt"],
+                                "unit": "env-steps/s", "ms_per_step": shard["dt"] / args.steps * 1e3, "steps": args.steps,
+                                "minibatch": sa.minibatch_size, "update_launch": launch_of(sa),
+                                "parity_checked": bool(sp["ok"]) if sp is not None else False, "parity": sp}
     sys.stdout.flush()
     os.write(json_fd, (json.dumps(out) + "\n").encode())
     D.shutdown()
     if parity is not None and not parity["ok"]:
         sys.exit("bench.py: the GPU's first update does NOT match the oracle's -- see \"parity\" in the line above")
+    if not shard_ok:
+        sys.exit("bench.py: the 512-envs/GPU shard's first update does NOT match the oracle's -- see \"config4_shard\" above")
 
 
 if __name__ == "__main__":

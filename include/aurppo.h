@@ -62,6 +62,12 @@ int aurppo_version(void);
 const char* aurppo_last_error(void);
 /* Number of gfx950 devices visible; <0 on HIP error.  Does not create a context on any of them. */
 int aurppo_device_count(void);
+/* Which build of the fused MLP step (K7) aurppo_mlp_ppo_*_f32 launches: 2 = k_mlp_step2 (v_mfma_f32_32x32x2_f32, fp32
+ * operands), 3 = k_mlp_step3 (v_mfma_f32_32x32x16_bf16 over three-way bf16 splits of the fp32 operands, six products,
+ * fp32 accumulate).  Same arguments, same results to the tolerances of tests/test_mlp_fused.py; environment variable
+ * AURPPO_K7_VARIANT overrides the built-in default.  (No reference counterpart: the policy nets are torch modules
+ * there, src/models/actor_critic.py:8-51.) */
+int aurppo_k7_variant(void);
 
 /* ---- K1: advantage estimation -------------------------------------------------------------
  * Replaces ppo.run_gae / ppo.normal_advantage (src/ppo.py:125-157; duplicates in
@@ -236,11 +242,12 @@ int aurppo_mlp_act_f32(const float* obs, const float* noise, int N, int D, int A
  * arguments and results as aurppo_mlp_ppo_step_ev_f32 / aurppo_mlp_act_f32 except
  *   layout_h: for the actor, then the critic: {w_0, b_0, ..., w_L, b_L} (L = num_layers; layer L is the head), then
  *             actor_logstd -- 4 * (num_layers + 1) + 1 float offsets into the bucket;
- *   workspace: aurppo_mlp_wide_workspace_bytes(n_params) bytes, 64-byte aligned (the act entry point uses it for the
- *             operand-order copy of the weights).
+ *   workspace: aurppo_mlp_wide_workspace_bytes(n_params, hidden, D) bytes, 64-byte aligned (slab region sized from the
+ *             shape); the act entry point only keeps the operand-order copy of the weights there and is content with
+ *             aurppo_mlp_wide_workspace_bytes(0, hidden, D).
  * ev_begin / ev_end (either may be NULL): hipEvent_t handles recorded around the main kernel.  The optimizer step that
  * follows is aurppo_clip_adam_f32 (K6b).                                                                              */
-size_t aurppo_mlp_wide_workspace_bytes(int n_params);
+size_t aurppo_mlp_wide_workspace_bytes(int n_params, int hidden, int state_dim);
 int aurppo_mlp_wide_ppo_step_f32(const float* obs, const float* actions, const float* rec, const int32_t* idx, int M,
                                  int D, int A, int continuous, int hidden, int num_layers, const float* params,
                                  const int* layout_h, int n_params, float* grads, double clip, double ent_coef,

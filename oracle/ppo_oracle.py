@@ -356,7 +356,7 @@ def reference_gae_torch(rewards, values, terminals, next_value, next_done, gamma
     return advantages + values, advantages
 
 
-def reference_update(policy, optimizer, buf, next_obs, next_done, hp, rng, collect=True):
+def reference_update(policy, optimizer, buf, next_obs, next_done, hp, rng, collect=True, stop_after=None, grads_out=None):
     """One update of the reference trainer on CPU torch tensors: bootstrap value + GAE
     (src/ppo.py:159-166), flatten (src/ppo.py:32-39), E epochs of shuffle + minibatch
     clipped-surrogate steps with ``clip_grad_norm_`` and Adam (src/ppo.py:213-273).
@@ -366,6 +366,10 @@ def reference_update(policy, optimizer, buf, next_obs, next_done, hp, rng, colle
     num_minibatches, clip_coeff, entropy_coeff, value_coeff, norm_adv, clip_vloss,
     max_grad_norm, target_kl.  ``rng``: numpy RandomState standing in for the global stream.
     Returns dict(returns, advantages, scalars=[per-minibatch 9-vector], perms=[per-epoch]).
+
+    Checker-only extras (defaults = the reference's behaviour): ``grads_out``, a list that receives the flattened
+    gradient of every optimizer step as ``loss.backward()`` left it (before ``clip_grad_norm_``); ``stop_after``, return
+    after that many optimizer steps (the multi-GPU parity of SURVEY 8e needs step 1 of every shard, nothing more).
     """
     torch = _torch()
     nn = torch.nn
@@ -392,6 +396,7 @@ def reference_update(policy, optimizer, buf, next_obs, next_done, hp, rng, colle
     b_inds = np.arange(B)
     out_scalars, perms = [], []
     approx_kl = None
+    n_opt_steps = 0
     for _ep in range(hp["num_update_epochs"]):
         rng.shuffle(b_inds)
         if collect:
@@ -424,12 +429,18 @@ def reference_update(policy, optimizer, buf, next_obs, next_done, hp, rng, colle
             loss = policy_loss - hp["entropy_coeff"] * entropy_loss + value_loss * hp["value_coeff"]
             optimizer.zero_grad()
             loss.backward()
+            if grads_out is not None:
+                grads_out.append(torch.cat([p.grad.reshape(-1) for p in policy.parameters()]).clone())
             nn.utils.clip_grad_norm_(policy.parameters(), hp["max_grad_norm"])
             optimizer.step()
             if collect:
                 out_scalars.append([x.detach().item() for x in (loss, policy_loss, value_loss, entropy_loss,
                                                                 old_approx_kl, approx_kl, clipfrac,
                                                                 adv_mean, adv_std)])
+            n_opt_steps += 1
+            if stop_after is not None and n_opt_steps >= stop_after:
+                return {"returns": returns, "advantages": advantages,
+                        "scalars": np.array(out_scalars, dtype=np.float64), "perms": perms}
         if hp.get("target_kl") is not None and approx_kl > hp["target_kl"]:
             break
     return {"returns": returns, "advantages": advantages,

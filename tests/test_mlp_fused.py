@@ -31,10 +31,11 @@ def _setup(T, N, D, A, seed=0, cont=True):
     return H, pol, bucket, obs, act, rec
 
 
-@pytest.fixture(params=["2", "1"], ids=["two-set", "one-set"])
+@pytest.fixture(params=["2", "3"], ids=["f32-mfma", "bf16x3-mfma"])
 def variant(request, monkeypatch):
-    """Both builds of K7: k_mlp_step2 (default) and k_mlp_step (AURPPO_MLP_VARIANT=1)."""
-    monkeypatch.setenv("AURPPO_MLP_VARIANT", request.param)
+    """Both builds of K7: k_mlp_step2 (fp32 MFMA) and k_mlp_step3 (bf16 MFMA over three-way splits, AURPPO_K7_VARIANT=3),
+    held to the SAME tolerances."""
+    monkeypatch.setenv("AURPPO_K7_VARIANT", request.param)
     return request.param
 
 

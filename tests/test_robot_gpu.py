@@ -72,26 +72,35 @@ def test_robot_train_runs_on_gpu():
     assert np.isfinite(a._last_scalars).all() and a._last_scalars.shape == (8, 9)
 
 
+@pytest.mark.parametrize("equivariant", [False, True], ids=["plain_cnn", "equivariant"])
 @pytest.mark.parametrize("C,S", [(1, 128), (3, 84)], ids=["config3_width", "config5_shard_width"])
-def test_robot_update_at_config_env_count_fused_blocks_equal_stock_blocks(C, S):
+def test_robot_update_at_config_env_count_fused_blocks_equal_stock_blocks(C, S, equivariant):
     """BASELINE configs 3 / 5 run 256 envs per GPU: one update at that env count (T = 2, two minibatches of 256 images), once
     with K9 in the encoder blocks and once with the stock torch ops (``fused_pool = False``), from the same weights, data
     and shuffle seed -- the loss scalars of every step and the final weights must agree (the CPU oracle is hours away at
-    this width; at N = 8 both paths are held to it above)."""
+    this width; at N = 8 both paths are held to it above).  ``equivariant``: the same with the C4-equivariant actor / critic
+    BASELINE configs 3 and 5 name (aur_ppo_amd/equiv.py, build-defined: e2cnn is absent; 32 regular
+    fields here so that the expanded filter banks stay test-sized) -- K10 / K9 blocks against the stock torch blocks."""
     from aur_ppo_amd.base_cnns import base_encoder
+    from aur_ppo_amd.equiv import _Block
     from aur_ppo_amd.robot_ppo import robot_ppo
     from aur_ppo_amd.robot_run import build_parser, params_from_args
     N, T = 256, 2
     p = params_from_args(build_parser().parse_args([]))
     p.update(gym_id="Synthetic-arm", num_envs=N, num_steps=T, total_timesteps=N * T, num_update_epochs=2, num_minibatches=2,
              do_pretraining=False, log=False, obs_size=S, obs_channels=C)
+    if equivariant:
+        p.update(equivariant=True, equiv_hidden=32)
     outs = []
     for fused in (True, False):
         torch.manual_seed(4)
         a = robot_ppo(p)
+        n_seams = 0
         for m in a.policy.modules():
-            if isinstance(m, base_encoder):
+            if isinstance(m, (base_encoder, _Block)):
                 m.fused_pool = fused
+                n_seams += 1
+        assert n_seams > 0
         g = torch.Generator(device="cuda").manual_seed(6)
         b = a.buffer
         b.states.copy_((torch.rand(T, N, device="cuda", generator=g) < 0.5).float())

@@ -122,3 +122,44 @@ def test_target_kl_early_stop_leaves_the_generator_where_numpy_would_be():
     key, pos = a.rng.get_state()
     np.testing.assert_array_equal(key, rs.get_state()[1])
     assert pos == rs.get_state()[2]
+
+
+def test_mid_run_checkpoint_and_resume_through_train(tmp_path):
+    """--checkpoint_path / --checkpoint_every write a checkpoint DURING the run; --resume continues from it: the remaining
+    updates only, no second pre-training phase (upstream writes one file at the very end and cannot resume,
+    src/robot_ppo.py:502-507)."""
+    path = str(tmp_path / "mid.pt")
+    torch.manual_seed(0)
+    a = robot_ppo(_params(total_timesteps=4 * 12, checkpoint_path=path, checkpoint_every=2, do_pretraining=True), ops=oracle_ops)
+    assert a.num_updates == 4
+    saved = []
+    save0 = a.save_checkpoint
+    a.save_checkpoint = lambda p, update=0: (saved.append(update), save0(p, update=update))
+    a.train()
+    assert saved == [2, 4]
+    sd = torch.load(path, weights_only=True)            # tensors, numbers, lists and dicts only
+    assert sd["update"] == 4 and {"actor_state", "critic_state", "optimizer_state", "trainer_state"} <= set(sd)
+    # resume from a checkpoint taken after update 2
+    b = robot_ppo(_params(total_timesteps=4 * 12, checkpoint_path=path, checkpoint_every=2, do_pretraining=True), ops=oracle_ops)
+    b.save_checkpoint(path, update=2)
+    c = robot_ppo(_params(total_timesteps=4 * 12, resume=path, do_pretraining=True), ops=oracle_ops)
+    c.pretrain = lambda *a_, **k: (_ for _ in ()).throw(AssertionError("a resumed run must not pre-train again"))
+    c.train()
+    n_updates = sum(1 for (t, _, _) in c.writer.scalars if t == "losses/policy_loss")
+    assert n_updates == 2
+
+
+def test_reference_format_checkpoint_loads(tmp_path):
+    """A file with upstream's three keys only (src/robot_ppo.py:502-507: actor_state, critic_state, optimizer_state)."""
+    a = robot_ppo(_params(), ops=oracle_ops)
+    ret, adv = a.advantages(*a.envs.reset(), torch.zeros(2), a.buffer, a.num_steps)
+    a.update(a.buffer.flatten(ret, adv), 1, a.batch_size, a.minibatch_size, [])          # gives the optimizer a state
+    path = str(tmp_path / "ref.pt")
+    torch.save({"actor_state": a.policy.actor.state_dict(), "critic_state": a.policy.critic.state_dict(),
+                "optimizer_state": a.optimizer.state_dict()}, path)
+    b = robot_ppo(_params(), ops=oracle_ops)
+    assert b.load_checkpoint(path) == 0
+    for (k, x), (_, y) in zip(a.policy.actor.state_dict().items(), b.policy.actor.state_dict().items()):
+        assert torch.equal(x, y), k
+    sa, sb = a.optimizer.state_dict()["state"], b.optimizer.state_dict()["state"]
+    assert sa.keys() == sb.keys() and all(torch.equal(sa[i]["exp_avg"], sb[i]["exp_avg"]) for i in sa)

@@ -133,3 +133,83 @@ def test_checkpoint_resume_continues_the_same_run(tmp_path):
     assert pa == pc
     sd = torch.load(path, weights_only=False)
     assert {"policy_state", "optimizer_state", "trainer_state", "update"} <= set(sd)
+
+
+class _EpisodeEnv:
+    """Fake arm runner with REAL episode semantics (what SyntheticArmEnv hides by redrawing every step): env i's
+    observation carries its step-in-episode count; an episode ends after ``length[i]`` steps; stepping a finished env
+    without a reset raises, as a terminal bulletarm env would misbehave."""
+    device_native = False
+
+    def __init__(self, n, lengths):
+        self.n, self.lengths = n, lengths
+        self.t = np.zeros(n, dtype=np.int64)
+        self.finished = np.zeros(n, dtype=bool)
+        self.resets = 0
+        self.stepped_past_terminal = False
+
+    def _obs(self):
+        o = torch.zeros(self.n, 1, 8, 8)
+        for i in range(self.n):
+            o[i] = float(self.t[i])
+        return torch.zeros(self.n), o
+
+    def reset(self):
+        self.t[:] = 0
+        self.finished[:] = False
+        return self._obs()
+
+    def getNextAction(self):
+        return torch.zeros(self.n, 5)
+
+    def step(self, actions, auto_reset=False):
+        if self.finished.any():
+            self.stepped_past_terminal = True
+        self.t += 1
+        dones = torch.tensor([float(self.t[i] >= self.lengths[i]) for i in range(self.n)])
+        rewards = dones.clone()
+        for i in range(self.n):
+            if dones[i] > 0:
+                if auto_reset:
+                    self.t[i] = 0
+                    self.resets += 1
+                else:
+                    self.finished[i] = True
+        states, obs = self._obs()
+        return states, obs, rewards, dones
+
+    def close(self):
+        pass
+
+
+def test_step_env_resets_finished_episodes_before_the_next_act_and_evaluates_on_upstream_cadence():
+    """src/trainer/ppoBulletTrainer.py:78-85 resets the done envs after every step, :166-168 / :177-178 evaluate during the
+    run.  A done env must come back as a FRESH episode (observation counter 0) in what step_env returns."""
+    torch.manual_seed(0)
+    np.random.seed(0)
+    agent = ppoBullet(num_processes=2, total_steps=500, num_minibatches=2, update_epochs=1, target_kl=1e9, ops=oracle_ops,
+                      clip_vloss=True)
+    agent.device = torch.device("cpu")
+    tr = ppoBulletTrainer(agent, total_time_steps=2 * 500, num_env_steps=500, num_processes=2, pretrain_episodes=0,
+                          num_eval_episodes=1)
+    tr.device = torch.device("cpu")
+    tr.do_pretraining = False
+    env = _EpisodeEnv(2, [3, 5])
+    tr.initialize_env = lambda *a, **k: (setattr(tr, "envs", env), setattr(tr, "eval_envs", _EpisodeEnv(1, [2])))
+    seen = []
+    act0 = agent.act
+
+    def spy_act(s, o, deterministic=False):
+        if not deterministic:
+            seen.append(o[:, 0, 0, 0].clone())
+        return act0(s, o, deterministic=deterministic)
+
+    agent.act = spy_act
+    pi, critic = Pi(), nn.Sequential(nn.Flatten(), nn.Linear(2 * 8 * 8, 1))
+    tr.run(None, {"obs_size": 8}, {}, "Synthetic-arm", pi, critic, "cnn", log=False)
+    assert not env.stepped_past_terminal and env.resets == 500 // 3 + 500 // 5
+    steps = torch.stack(seen)                     # (500, 2): the step-in-episode counter the policy saw
+    assert steps[:, 0].max() == 2 and steps[:, 1].max() == 4          # never an observation from beyond the terminal step
+    assert torch.equal(steps[:7, 0], torch.tensor([0., 1., 2., 0., 1., 2., 0.]))
+    evals = [g for (t, _, g) in tr.writer.scalars if t == "charts/eval_discounted_episodic_return"]
+    assert evals == [0, 1000]                     # before the run, and after the update that ends on global_step % 1000 == 0
