@@ -17,6 +17,7 @@
 #include <stdlib.h>
 
 #include "adam_math.h"
+#include "bf16x3.h"
 #include "mlp_common.h"
 
 using namespace aurppo_mlp;
@@ -317,6 +318,7 @@ __global__ __launch_bounds__(kThreads) void k_adam_chain(float* __restrict__ p, 
                                                          const float* __restrict__ step, double beta1, double beta2,
                                                          double eps, float* __restrict__ out_norm, float gscale, int nb_upd,
                                                          int w1_actor, int w1_critic, int D, float* __restrict__ w1op,
+                                                         int w2_actor, int w2_critic, unsigned short* __restrict__ wop3,
                                                          const float4* __restrict__ rec, int rec_stride,
                                                          const int32_t* __restrict__ next_idx, int next_M,
                                                          double (*__restrict__ stats)[2]) {
@@ -385,10 +387,28 @@ __global__ __launch_bounds__(kThreads) void k_adam_chain(float* __restrict__ p, 
             }
             const int ea = i - w1_actor, ec = i - w1_critic;
             const int e = (ea >= 0 && ea < H * D) ? ea : ((ec >= 0 && ec < H * D) ? ec : -1);
-            if (e >= 0) {
+            if (e >= 0 && w1op) {
                 const int net = (ea >= 0 && ea < H * D) ? 0 : 1;
                 const int row = e / D, k = e - row * D;
                 w1op[((net * 2 + (row >> 5)) * 32 + (k >> 1)) * kWave + (row & 31) + 32 * (k & 1)] = pn;
+            }
+            if (wop3) {      // k_mlp_step3's copies: the bf16 planes of the new value, W1 once, W2 forward and backward
+                const int e2a = i - w2_actor, e2c = i - w2_critic;
+                const int e2 = (e2a >= 0 && e2a < H * H) ? e2a : ((e2c >= 0 && e2c < H * H) ? e2c : -1);
+                if (e >= 0 || e2 >= 0) {
+                    const bool is_w2 = e < 0;
+                    const int net = is_w2 ? ((e2a >= 0 && e2a < H * H) ? 0 : 1) : ((ea >= 0 && ea < H * D) ? 0 : 1);
+                    const int row = is_w2 ? e2 / H : e / D, col = is_w2 ? e2 % H : e - (e / D) * D;
+                    int at[2];
+                    const int n_at = bf3::wop3_places(net, is_w2 ? 1 : 0, row, col, at);
+                    unsigned p0, p1, p2;
+                    bf3::split3(pn, 0.0f, p0, p1, p2);
+                    for (int q = 0; q < n_at; ++q) {
+                        wop3[at[q]] = (unsigned short)p0;
+                        wop3[at[q] + bf3::kWopBlock] = (unsigned short)p1;
+                        wop3[at[q] + 2 * bf3::kWopBlock] = (unsigned short)p2;
+                    }
+                }
             }
         }
     } else {
@@ -413,7 +433,7 @@ __global__ __launch_bounds__(kThreads) void k_adam_chain(float* __restrict__ p, 
 extern "C" size_t aurppo_mlp_workspace_bytes(int n_params) {
     return sizeof(double) * 2 * kStatBlocks + sizeof(double) * 8 * kMaxGrid + sizeof(float) * (size_t)kMaxGrid * (size_t)n_params + 64 +
            sizeof(unsigned long long) * 40 * kMaxGrid + sizeof(float) * 4 * 32 * 64 + 64 +
-           sizeof(double) * (size_t)((n_params + 63) / 64) + 64;
+           ((sizeof(double) * (size_t)((n_params + 63) / 64) + 63) / 64) * 64 + 64 + mlp_step3_wop_bytes() + 64;
 }
 
 namespace {
@@ -439,6 +459,7 @@ struct WsView {   // carve-up of the caller's workspace (aurppo_mlp_workspace_by
     float* w1op;                 // W1 in B-operand order
     unsigned* tile_counter;
     double* sq_part;             // clip partial sums, one per k_mlp_reduce workgroup
+    unsigned short* wop3;        // k_mlp_step3: bf16 planes of W1 / W2 in operand order
 };
 WsView ws_view(void* workspace, int n_params) {
     WsView v;
@@ -451,6 +472,8 @@ WsView ws_view(void* workspace, int n_params) {
     v.w1op = reinterpret_cast<float*>(v.stamps + 40 * kMaxGrid);
     v.tile_counter = reinterpret_cast<unsigned*>(v.w1op + 4 * 32 * 64);
     v.sq_part = reinterpret_cast<double*>(v.tile_counter + 16);
+    v.wop3 = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(v.sq_part) +
+                                               ((sizeof(double) * (size_t)((n_params + 63) / 64) + 63) / 64) * 64);
     return v;
 }
 int stat_blocks_for(int M) {
@@ -505,11 +528,16 @@ static int mlp_step_impl(const float* obs, const float* actions, const float* re
     a.w1op = wv.w1op;
     a.tile_counter = wv.tile_counter;
     a.static_tiles = knobs.static_tiles ? 1 : 0;
+    a.wop3 = wv.wop3;
     double* sq_part = wv.sq_part;
     if (!(chain && chain->chained)) {   // otherwise the previous chained call has prepared all of this
         hipLaunchKernelGGL(k_adv_stats_idx, dim3(sb), dim3(kThreads), 0, s, a.rec, a.rec_stride, idx, M,
                            reinterpret_cast<double (*)[2]>(stats), params, a.L.w1[0], a.L.w1[1], D, a.w1op, a.tile_counter);
         AURPPO_LAUNCH_CHECK("k_adv_stats_idx");
+        if (variant == 3) {
+            const int rc = launch_mlp3_prep(params, a.L, D, wv.wop3, s);
+            if (rc != AURPPO_OK) return rc;
+        }
     }
     const int n_tiles = (M + R - 1) / R;
     // One persistent workgroup per CU, minus one CU per XCD (AURPPO_MLP_SPARE_CUS, default 8; workgroups are dealt
@@ -531,10 +559,9 @@ static int mlp_step_impl(const float* obs, const float* actions, const float* re
     if (grid > (n_tiles + 1) / 2) grid = (n_tiles + 1) / 2;     // two tile sets per workgroup
     if (ev_begin) AURPPO_HIP_TRY(hipEventRecord((hipEvent_t)ev_begin, s));
     {
-        const int rc = launch_mlp_step2(a, grid, s);
+        const int rc = variant == 3 ? launch_mlp_step3(a, grid, s) : launch_mlp_step2(a, grid, s);
         if (rc != AURPPO_OK) return rc;
     }
-    (void)variant;
     if (ev_end) AURPPO_HIP_TRY(hipEventRecord((hipEvent_t)ev_end, s));
     const int n_red = (n_params + 63) / 64;
     hipLaunchKernelGGL(k_mlp_reduce<1>, dim3(n_red), dim3(1024), 0, s, a.slabs, a.loss_part, grid, n_params, a.h, grads,
@@ -548,7 +575,8 @@ static int mlp_step_impl(const float* obs, const float* actions, const float* re
         hipLaunchKernelGGL(k_adam_chain, dim3(nb_upd + nsb), dim3(kThreads), 0, s, chain->params_rw, grads, chain->exp_avg,
                            chain->exp_avg_sq, n_params, sq_part, n_red, (float)chain->max_norm, chain->lr_dev,
                            chain->step_dev, chain->beta1, chain->beta2, chain->eps, chain->out_norm, 1.0f, nb_upd, a.L.w1[0],
-                           a.L.w1[1], D, a.w1op, a.rec, a.rec_stride, chain->next_idx, chain->next_M,
+                           a.L.w1[1], D, a.w1op, a.L.w2[0], a.L.w2[1], variant == 3 ? wv.wop3 : (unsigned short*)nullptr,
+                           a.rec, a.rec_stride, chain->next_idx, chain->next_M,
                            reinterpret_cast<double (*)[2]>(stats));
         AURPPO_LAUNCH_CHECK("k_adam_chain");
     }
@@ -579,7 +607,8 @@ int aurppo_mlp::launch_adam_tail(float* params, float* grads, float* exp_avg, fl
     // no operand-order copy of W1 (offsets past the bucket), no statistics for a next minibatch
     hipLaunchKernelGGL(k_adam_chain, dim3(nb_upd), dim3(kThreads), 0, s, params, grads, exp_avg, exp_avg_sq, n_params, sq_part,
                        (n_params + 63) / 64, (float)max_norm, lr_dev, step_dev, beta1, beta2, eps, out_norm, 1.0f, nb_upd, n_params,
-                       n_params, 1, (float*)nullptr, (const float4*)nullptr, 1, (const int32_t*)nullptr, 0,
+                       n_params, 1, (float*)nullptr, n_params, n_params, (unsigned short*)nullptr, (const float4*)nullptr, 1,
+                       (const int32_t*)nullptr, 0,
                        (double (*)[2]) nullptr);
     AURPPO_LAUNCH_CHECK("k_adam_chain");
     return AURPPO_OK;
@@ -655,7 +684,8 @@ extern "C" int aurppo_mlp_ppo_apply_f32(float* params, float* grads, float* exp_
     const int nsb = next_idx ? stat_blocks_for(next_M) : 0;
     hipLaunchKernelGGL(k_adam_chain, dim3(nb_upd + nsb), dim3(kThreads), 0, (hipStream_t)stream, params, grads, exp_avg,
                        exp_avg_sq, n_params, (const double*)nullptr, 0, (float)max_norm, lr_dev, step_dev, beta1, beta2, eps,
-                       out_norm, (float)grad_scale, nb_upd, layout_h[0], layout_h[6], D, w1op,
+                       out_norm, (float)grad_scale, nb_upd, layout_h[0], layout_h[6], D, w1op, layout_h[2], layout_h[8],
+                       aurppo_knobs().k7_variant == 3 ? wv.wop3 : (unsigned short*)nullptr,
                        reinterpret_cast<const float4*>(rec), rec_floats == 16 ? 4 : 1, next_idx, next_idx ? next_M : 0,
                        reinterpret_cast<double (*)[2]>(stats));
     AURPPO_LAUNCH_CHECK("k_adam_chain");

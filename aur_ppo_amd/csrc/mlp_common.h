@@ -39,6 +39,7 @@ struct MlpArgs {
     unsigned long long* stamps;  // diagnostic build: (grid, 16) cycle counters
     unsigned* tile_counter;  // two-set kernel: next tile to hand out (zeroed by k_adv_stats_idx)
     float* w1op;           // two-set kernel: W1 slices in MFMA B-operand order, [4 waves][32 k-steps][64 lanes]
+    const void* wop3;      // k_mlp_step3: bf16 planes of W1 / W2 in operand order (bf16x3.h)
     const double* stats;   // (kStatBlocks, 2) advantage partial sums
     int n_stat_blocks;
     int D, A;
@@ -167,6 +168,11 @@ __device__ __forceinline__ f32x16 zero16() {
 // mlp2.hip: the two-tile-set variant of K7 (8 waves per workgroup); same arguments, same slab / loss_part outputs.
 size_t mlp_step2_lds_bytes();
 int launch_mlp_step2(const MlpArgs& a, int grid, hipStream_t s);
+// mlp3.hip: the same step on bf16 MFMAs over three-way bf16 splits (AURPPO_K7_VARIANT=3); its operand-order weight copies
+size_t mlp_step3_lds_bytes();
+size_t mlp_step3_wop_bytes();
+int launch_mlp3_prep(const float* params, const MlpLayout& L, int D, void* wop3, hipStream_t s);
+int launch_mlp_step3(const MlpArgs& a, int grid, hipStream_t s);
 // mlp.hip: k_mlp_reduce alone (grads[p] = fixed-order sum over n_slabs slabs, loss scalars folded) -- mlp_wide.hip's tail.
 // sq_part / step_dev != nullptr: also leave the clip's partial sums of squares (one per 64 parameters) and advance the
 // Adam step count -- what launch_adam_tail (k_adam_chain without K7's extras: clip + Adam in one launch) then consumes.

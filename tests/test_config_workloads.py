@@ -72,9 +72,15 @@ def test_k3_gathers_image_rows_bit_exact_at_config_minibatch(T, N, C, S, M):
 @pytest.mark.parametrize("T,N,C,S,M", CONFIGS)
 def test_first_block_at_config_minibatch_matches_torch_on_slices(T, N, C, S, M):
     """K10 (conv 3x3 over [image, tiled state] + ReLU + 2x2 max-pool, forward and weight / bias gradients) on a whole
-    minibatch of the config; values against torch's direct fp32 convolution on slices of it, gradients against the sum of
-    the same reference over 8 chunks of 64 samples taken across the batch (the full-batch torch reference would materialise
-    the 8.6 GB pre-pool tensor this kernel exists to avoid)."""
+    minibatch of the config (the full-batch torch reference would materialise the 8.6 GB pre-pool tensor this kernel
+    exists to avoid, so:)
+      * values against torch's direct fp32 convolution on 8 chunks of 64 samples taken across the batch;
+      * gradients: the upstream gradient is zero outside those chunks, so the full-batch result must equal the SUM of the
+        same kernel's results on the chunks alone (a per-sample kernel: same decisions, fixed-order sums) to rounding;
+      * each chunk's gradient against torch's on that chunk.  A weight-gradient element sums 64 x 16 x (S/2)^2 routed
+        products; where two elements of a pooling window (or a pre-activation and 0) are within an ulp the two
+        implementations may route differently, each such window moving an element by ~|gy * x| <= 1: 1e-3 of the
+        tensor's largest element (~600 at this size) covers it; the small shapes of tests/test_hip_parity.py hold 2e-5."""
     import torch.nn.functional as F
     from aur_ppo_amd import hip_ops as H
     g = torch.Generator(device="cuda").manual_seed(M)
@@ -84,22 +90,31 @@ def test_first_block_at_config_minibatch_matches_torch_on_slices(T, N, C, S, M):
     b = (0.1 * torch.randn(16, device="cuda", generator=g)).requires_grad_(True)
     y = H.first_block(obs, state, w, b)
     assert y.shape == (M, 16, S // 2, S // 2)
-    # gradient weights that are zero outside the checked chunks, so the full-batch gradient equals the chunks' sum
     chunks = [(k * (M // 8), k * (M // 8) + 64) for k in range(8)]
     gy = torch.zeros_like(y)
     for lo, hi in chunks:
         gy[lo:hi] = torch.randn(hi - lo, 16, S // 2, S // 2, device="cuda", generator=g)
     (y * gy).sum().backward()
-    w1, b1 = w.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+    sum_w, sum_b = torch.zeros_like(w), torch.zeros_like(b)
     with torch.backends.cudnn.flags(enabled=False):
         for lo, hi in chunks:
+            wk, bk = w.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+            yk = H.first_block(obs[lo:hi].contiguous(), state[lo:hi].contiguous(), wk, bk)
+            assert torch.equal(yk, y[lo:hi])
+            (yk * gy[lo:hi]).sum().backward()
+            sum_w += wk.grad
+            sum_b += bk.grad
+            w1, b1 = w.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
             x = torch.cat([obs[lo:hi], state[lo:hi].view(-1, 1, 1, 1).expand(hi - lo, 1, S, S)], 1)
             ref = F.max_pool2d(F.relu(F.conv2d(x, w1, b1, padding=1)), 2)
             torch.testing.assert_close(y[lo:hi], ref, rtol=1e-5, atol=2e-6)
             (ref * gy[lo:hi]).sum().backward()
-    sw, sb = float(w1.grad.abs().max()), float(b1.grad.abs().max())
-    assert float((w.grad - w1.grad).abs().max()) <= 2e-5 * sw + 1e-6, (float((w.grad - w1.grad).abs().max()), sw)
-    assert float((b.grad - b1.grad).abs().max()) <= 2e-5 * sb + 1e-6
+            sw, sb = float(w1.grad.abs().max()), float(b1.grad.abs().max())
+            assert float((wk.grad - w1.grad).abs().max()) <= 1e-3 * sw, (float((wk.grad - w1.grad).abs().max()), sw)
+            assert float((bk.grad - b1.grad).abs().max()) <= 1e-3 * sb, (float((bk.grad - b1.grad).abs().max()), sb)
+    sw, sb = float(sum_w.abs().max()), float(sum_b.abs().max())
+    assert float((w.grad - sum_w).abs().max()) <= 2e-5 * sw + 1e-6, (float((w.grad - sum_w).abs().max()), sw)
+    assert float((b.grad - sum_b).abs().max()) <= 2e-5 * sb + 1e-6, (float((b.grad - sum_b).abs().max()), sb)
 
 
 @pytest.mark.parametrize("T,N,C,S,M", CONFIGS)
