@@ -25,6 +25,21 @@
 using namespace aurppo_mlp;
 using namespace bf3;
 
+// Diagnostic build only (tools/mlp_stamps.py): wave 0 of each set accumulates, per phase, the cycles it spent working
+// (slot k) and waiting at the phase's barrier (slot 8 + k) in LDS; dumped to the workspace at the end.
+#ifdef AURPPO_MLP_STAMPS
+#define STAMP3(k)                                                              \
+    do {                                                                       \
+        if (w == 0 && lane == 0) {                                             \
+            const unsigned long long t__ = __builtin_readcyclecounter();       \
+            s_stamp[set][k] += t__ - st_last;                                  \
+            st_last = t__;                                                     \
+        }                                                                      \
+    } while (0)
+#else
+#define STAMP3(k) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int kThreads3 = 512;
@@ -63,6 +78,50 @@ constexpr int kSmallOff = kParkBytes;                // float [8 waves][8][5]
 constexpr int kGbOff = kSmallOff + 4 * 8 * 8 * 5;    // float [4 roles][2][32]
 static_assert(kGbOff + 4 * 4 * 2 * 32 <= kDynBytes, "hand-over scratch must fit the dead tiles");
 
+// Epilogues, four values (one 8-byte store per plane) at a time so that nothing but the accumulator is live across them.
+// tanh(acc + bias) of a 32x32 block into an F image:
+__device__ __forceinline__ void tanh_store(char* img, int f0, const f32x16& acc, float bias, int lane) {
+    const int f = f0 + (lane & 31), h = lane >> 5;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+        unsigned a0, a1, a2, b0, b1, b2;
+        split3(tanh_fast(acc[4 * gq + 0] + bias), tanh_fast(acc[4 * gq + 1] + bias), a0, a1, a2);
+        split3(tanh_fast(acc[4 * gq + 2] + bias), tanh_fast(acc[4 * gq + 3] + bias), b0, b1, b2);
+        const int o = foff(f, 8 * gq + 4 * h);
+        *reinterpret_cast<u32x2*>(img + 0 * kFPlane + o) = u32x2{a0, b0};
+        *reinterpret_cast<u32x2*>(img + 1 * kFPlane + o) = u32x2{a1, b1};
+        *reinterpret_cast<u32x2*>(img + 2 * kFPlane + o) = u32x2{a2, b2};
+    }
+}
+// dZ = dH * (1 - h^2) over the block of h that sits in the image, written back in its place; returns the lane's column sum
+__device__ __forceinline__ float dz_in_place(char* img, int f0, const f32x16& dh, int lane) {
+    const int f = f0 + (lane & 31), h = lane >> 5;
+    float colsum = 0.0f;
+    u32x2 q[4][3];
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {      // all twelve reads go out together
+        const int o = foff(f, 8 * gq + 4 * h);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) q[gq][p] = *reinterpret_cast<const u32x2*>(img + p * kFPlane + o);
+    }
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+        const float h0 = join_lo(q[gq][0].x, q[gq][1].x, q[gq][2].x), h1 = join_hi(q[gq][0].x, q[gq][1].x, q[gq][2].x);
+        const float h2 = join_lo(q[gq][0].y, q[gq][1].y, q[gq][2].y), h3 = join_hi(q[gq][0].y, q[gq][1].y, q[gq][2].y);
+        const float d0 = dh[4 * gq + 0] * (1.0f - h0 * h0), d1 = dh[4 * gq + 1] * (1.0f - h1 * h1);
+        const float d2 = dh[4 * gq + 2] * (1.0f - h2 * h2), d3 = dh[4 * gq + 3] * (1.0f - h3 * h3);
+        colsum += (d0 + d1) + (d2 + d3);
+        unsigned a0, a1, a2, b0, b1, b2;
+        split3(d0, d1, a0, a1, a2);
+        split3(d2, d3, b0, b1, b2);
+        const int o = foff(f, 8 * gq + 4 * h);
+        *reinterpret_cast<u32x2*>(img + 0 * kFPlane + o) = u32x2{a0, b0};
+        *reinterpret_cast<u32x2*>(img + 1 * kFPlane + o) = u32x2{a1, b1};
+        *reinterpret_cast<u32x2*>(img + 2 * kFPlane + o) = u32x2{a2, b2};
+    }
+    return colsum;
+}
+
 __device__ __forceinline__ void lds_add(double* p, double v) {
     (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -77,6 +136,11 @@ __global__ __launch_bounds__(kThreads3, 1) void k_mlp_step3(const MlpArgs a) {
     __shared__ int s_grab;
     __shared__ int s_bar[2];
     __shared__ int s_pbar[2][2];
+#ifdef AURPPO_MLP_STAMPS
+    __shared__ unsigned long long s_stamp[2][16];
+    unsigned long long st_last = 0;
+    const unsigned long long rt_entry = wall_clock64();
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -311,6 +375,12 @@ __global__ __launch_bounds__(kThreads3, 1) void k_mlp_step3(const MlpArgs a) {
         return f;
     };
     const int nks1 = (D + 15) >> 4;              // k-steps of layer 1 that hold anything (X and W1 are zero beyond D)
+#ifdef AURPPO_MLP_STAMPS
+    if (tid < 32) (&s_stamp[0][0])[tid] = 0ull;
+    __syncthreads();
+    st_last = __builtin_readcyclecounter();
+    const unsigned long long clk0 = st_last, rt0 = wall_clock64();
+#endif
 
     for (int it = 0; s_first[set] != 0; ++it) {
         int ln = lane, sl = st;
@@ -341,7 +411,9 @@ __global__ __launch_bounds__(kThreads3, 1) void k_mlp_step3(const MlpArgs a) {
             }
             if (w == 0 && sl == 0) s_next[set][it & 1] = t1 < n_tiles ? 1 : 0;
         }
+        STAMP3(0);
         set_bar();
+        STAMP3(8);
         {   // ---- F1: H1 = tanh(X W1^T + b1): A = rows of the X image, B = the streamed W1 slice
             f32x16 acc = zero16();
 #pragma unroll
@@ -349,25 +421,20 @@ __global__ __launch_bounds__(kThreads3, 1) void k_mlp_step3(const MlpArgs a) {
                 if (ks < nks1) acc = mma32x3(x_rows(sX, ks, ln), wfrag(ks), acc);
             __builtin_amdgcn_sched_barrier(0);
             load_w(1);                                   // W2 (forward) arrives behind the epilogue and the barrier
-            prefetch(sIdx + ((it + 1) & 1) * R, sl);     // rows of tile it+1
-            const float bias = sB1[net * H + cb * 32 + (ln & 31)];
-            float v[16];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) v[e] = tanh_fast(acc[e] + bias);
-            store_acc_f(sH1, cb * 32, v, ln);
+            tanh_store(sH1, cb * 32, acc, sB1[net * H + cb * 32 + (ln & 31)], ln);
         }
+        STAMP3(1);
         pair_bar();
+        STAMP3(9);
         {   // ---- F2: H2 = tanh(H1 W2^T + b2): A = the H1 image read across its rows
             f32x16 acc = zero16();
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) acc = mma32x3(f_cols(sH1, ks, ln), wfrag(ks), acc);
-            const float bias = sB2[net * H + cb * 32 + (ln & 31)];
-            float v[16];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) v[e] = tanh_fast(acc[e] + bias);
-            store_acc_f(sH2, cb * 32, v, ln);
+            tanh_store(sH2, cb * 32, acc, sB2[net * H + cb * 32 + (ln & 31)], ln);
         }
+        STAMP3(2);
         pair_bar();
+        STAMP3(10);
         {   // ---- F3: head, 16 rows per wave on 16x16x32: out[s][a] = H2[s][:] . W3[a][:] + b3[a]
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -378,7 +445,9 @@ __global__ __launch_bounds__(kThreads3, 1) void k_mlp_step3(const MlpArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) sOut[(net * R + cb * 16 + 4 * (ln >> 4) + e) * LDO + col] = acc[e] + bias;
         }
+        STAMP3(3);
         set_bar();
+        STAMP3(11);
         {   // ---- L: distribution + PPO terms, 8 lanes per row; the head gradients go out as bf16 planes ([a][s] image)
             if (w == 0) {
                 const int t3 = dyn_base + __builtin_amdgcn_readfirstlane(t3_raw);
@@ -425,6 +494,9 @@ __global__ __launch_bounds__(kThreads3, 1) void k_mlp_step3(const MlpArgs a) {
                 d0 = (real && k0 < A) ? t.g_logp * ((k0 == ai ? 1.0f : 0.0f) - p0) + g_ent * (-p0 * (lp0 + ent)) : 0.0f;
                 d1 = (real && k1 < A) ? t.g_logp * ((k1 == ai ? 1.0f : 0.0f) - p1) + g_ent * (-p1 * (lp1 + ent)) : 0.0f;
             }
+            // rows of tile it+1 (its indices landed in LDS two tiles ago): issued here, landed at the next S -- five phases
+            // cover the HBM latency, and the 16 registers they arrive in are not live through the forward phases
+            prefetch(sIdx + ((it + 1) & 1) * R, sl);
             char* const doA = base + pDo;                 // actor's dOut image
             store_plain1(doA, kDoRow, kDoPlane, k0, lr, d0);
             store_plain1(doA, kDoRow, kDoPlane, k1, lr, d1);
@@ -441,7 +513,9 @@ __global__ __launch_bounds__(kThreads3, 1) void k_mlp_step3(const MlpArgs a) {
                 }
             }
         }
+        STAMP3(4);
         set_bar();
+        STAMP3(12);
         {   // ---- B1: dH2 = dOut W3 (one K = 16 step), dW3 += dOut^T H2, dZ2 in place over this wave's half of H2
             f32x16 acc = zero16();
             acc = mma32x3(plain_cols(sDo, kDoRow, kDoPlane, 0, 0, ln), plain_cols(sW3, kW3Row, kW3Plane, 0, cb * 32, ln), acc);
@@ -450,22 +524,15 @@ __global__ __launch_bounds__(kThreads3, 1) void k_mlp_step3(const MlpArgs a) {
 #pragma unroll
                 for (int q = 0; q < 2; ++q) gW3[q] = mma16x3(da, f_rows16(sH2, cb * 32 + 16 * q, ln), gW3[q]);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            load_w(2);                                   // W2 (backward) for B2's dH1
-            float hv[16], dz[16];
-            load_acc_f(sH2, cb * 32, hv, ln);
-            float colsum = 0.0f;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                dz[e] = acc[e] * (1.0f - hv[e] * hv[e]);
-                colsum += dz[e];
-            }
-            store_acc_f(sH2, cb * 32, dz, ln);
+            float colsum = dz_in_place(sH2, cb * 32, acc, ln);
             colsum += __shfl_xor(colsum, 32, kWave);
             gb2 += colsum;
         }
+        STAMP3(5);
         pair_bar();
+        STAMP3(13);
         {   // ---- B2: dW2 += dZ2^T H1 (this wave's in-block), dH1 = dZ2 W2 -> dZ1 in place over this wave's half of H1
+            load_w(2);                                   // W2 (backward) for dH1, behind the dW2 chains
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const Frag3 hb = f_rows(sH1, cb * 32, ks, ln);
@@ -475,19 +542,13 @@ __global__ __launch_bounds__(kThreads3, 1) void k_mlp_step3(const MlpArgs a) {
             f32x16 acc = zero16();
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) acc = mma32x3(f_cols(sH2, ks, ln), wfrag(ks), acc);
-            float hv[16], dz[16];
-            load_acc_f(sH1, cb * 32, hv, ln);
-            float colsum = 0.0f;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                dz[e] = acc[e] * (1.0f - hv[e] * hv[e]);
-                colsum += dz[e];
-            }
-            store_acc_f(sH1, cb * 32, dz, ln);
+            float colsum = dz_in_place(sH1, cb * 32, acc, ln);
             colsum += __shfl_xor(colsum, 32, kWave);
             gb1 += colsum;
         }
+        STAMP3(6);
         pair_bar();
+        STAMP3(14);
         {   // ---- B3: dW1 += dZ1^T X (this wave's 32 state columns), B = the X image read across its rows
             if (cb * 32 < D) {
 #pragma unroll
@@ -500,10 +561,20 @@ __global__ __launch_bounds__(kThreads3, 1) void k_mlp_step3(const MlpArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             load_w(0);                                   // W1 slice for the next tile's F1
         }
+        STAMP3(7);
         set_bar();
+        STAMP3(15);
         if (!s_next[set][it & 1]) break;
     }
+#ifdef AURPPO_MLP_STAMPS
+    const unsigned long long rt_loop_end = wall_clock64();
+#endif
     __syncthreads();   // the hand-over below reuses the tile memory: both sets must have left the loop
+#ifdef AURPPO_MLP_STAMPS
+    const unsigned long long rt_both_done = wall_clock64();
+    unsigned long long my_stamp = 0;
+    if (tid < 32) my_stamp = (&s_stamp[0][0])[tid];
+#endif
 
     int le = lane, se = st;
     asm volatile("" : "+v"(le), "+v"(se));
@@ -596,6 +667,18 @@ __global__ __launch_bounds__(kThreads3, 1) void k_mlp_step3(const MlpArgs a) {
             }
         }
     }
+#ifdef AURPPO_MLP_STAMPS
+    if (tid < 32) a.stamps[(size_t)blockIdx.x * 40 + tid] = my_stamp;
+    if (tid == 0) {
+        a.stamps[(size_t)blockIdx.x * 40 + 32] = __builtin_readcyclecounter() - clk0;
+        a.stamps[(size_t)blockIdx.x * 40 + 33] = wall_clock64() - rt0;
+        a.stamps[(size_t)blockIdx.x * 40 + 34] = rt_entry;
+        a.stamps[(size_t)blockIdx.x * 40 + 35] = rt0 - rt_entry;
+        a.stamps[(size_t)blockIdx.x * 40 + 36] = rt_loop_end - rt0;
+        a.stamps[(size_t)blockIdx.x * 40 + 37] = rt_both_done - rt_loop_end;
+        a.stamps[(size_t)blockIdx.x * 40 + 38] = wall_clock64() - rt_both_done;
+    }
+#endif
 }
 
 // wop3[...] = the bf16 planes of W1 / W2 of both nets in operand order (bf16x3.h), written destination-first so that the

@@ -1,7 +1,6 @@
 """Diagnostic: build the MLP kernels with -DAURPPO_MLP_STAMPS into a SEPARATE library, run one fused step at the
 BASELINE minibatch size and print cycle shares per phase (median over workgroups).
-AURPPO_MLP_VARIANT=1: wave 0 of k_mlp_step.  Default (2): wave 0 of each tile set of k_mlp_step2, work and
-barrier-wait cycles per phase."""
+Wave 0 of each tile set of k_mlp_step2 (default) or k_mlp_step3 (AURPPO_K7_VARIANT=3): work and barrier-wait cycles per phase."""
 import ctypes as C, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -26,18 +25,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 ws = H._ws_cache[("mlp", torch.cuda.current_device())]
 off = ((8 * (2 * 256 + 8 * 256) + 4 * 256 * n + 63) // 64) * 64
-variant = os.environ.get("AURPPO_MLP_VARIANT", "2")
-if variant == "1":
-    st = ws[off:off + 8 * 16 * 256].view(torch.int64).view(256, 16).cpu().numpy().astype(np.float64)
-    names = ["land X/act->LDS+bar", "issue prefetch", "L1 mma+tanh+bar", "L2 mma+tanh+bar", "head mma+bar", "loss lanes+bar",
-             "dH2,dZ2,dW3+bar", "dW2,dH1,dZ1+bar", "dZ1->LDS+bar", "dW1+bar", "(pre-slab)", "slab+reduce tail"]
-    st = st[st[:, 2] > 0]
-    med = np.median(st, axis=0)
-    tot = med[:12].sum()
-    for k, nm in enumerate(names):
-        print(f"{nm:24s} {med[k]:12.0f} cycles  {100 * med[k] / tot:5.1f} %")
-    print("total cycles (wave 0, median WG):", tot, " tiles per WG:", M // 32 // 256)
-else:
+if True:
     raw = ws[off:off + 8 * 40 * 256].view(torch.int64).view(256, 40).cpu().numpy().astype(np.float64)
     raw = raw[(raw[:, 1] > 0) & (raw[:, 35] > 0) & (raw[:, 35] < 1e6) & (raw[:, 36] > 0) & (raw[:, 36] < 1e7)]   # workgroups of this launch
     cyc, ticks = np.median(raw[:, 32]), np.median(raw[:, 33])
