@@ -47,7 +47,10 @@ extern "C" const char* aurppo_last_error(void) { return g_err; }
 
 extern "C" int aurppo_version(void) { return AURPPO_VERSION; }
 
-extern "C" int aurppo_k7_variant(void) { return aurppo_knobs().k7_variant == 3 ? 3 : 2; }
+extern "C" int aurppo_k7_variant(void) {
+    const int v = aurppo_knobs().k7_variant;
+    return (v == 3 || v == 4) ? v : 2;
+}
 
 extern "C" int aurppo_device_count(void) {
     int n = 0;

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void k_adv_stats_idx(const float4* __restrict_
                                                        unsigned* __restrict__ tile_counter) {
     __shared__ double sc[2][kThreads / kWave];
     if (w1op) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) *tile_counter = 0u;
+        if (blockIdx.x == 0 && threadIdx.x < 2) tile_counter[threadIdx.x] = 0u;
         for (int e = blockIdx.x * kThreads + threadIdx.x; e < 4 * 32 * 64; e += gridDim.x * kThreads) {
             const int lane = e & 63, m = (e >> 6) & 31, w = e >> 11;
             const int row = (w & 1) * 32 + (lane & 31), k = 2 * m + (lane >> 5);
@@ -280,7 +280,8 @@ __global__ __launch_bounds__(1024) void k_mlp_reduce(const float* __restrict__ s
         }
         if (step_dev && pi == 0 && blockIdx.x == 0) {
             *step_dev += 1.0f;   // the Adam kernel (a later launch) reads the new step count
-            *tile_counter = 0u;
+            tile_counter[0] = 0u;
+            tile_counter[1] = 0u;
         }
     }
     __shared__ double r[6];
@@ -319,6 +320,7 @@ __global__ __launch_bounds__(kThreads) void k_adam_chain(float* __restrict__ p, 
                                                          double eps, float* __restrict__ out_norm, float gscale, int nb_upd,
                                                          int w1_actor, int w1_critic, int D, float* __restrict__ w1op,
                                                          int w2_actor, int w2_critic, unsigned short* __restrict__ wop3,
+                                                         int w3_actor, int w3_critic, int A, int wop_mode,
                                                          const float4* __restrict__ rec, int rec_stride,
                                                          const int32_t* __restrict__ next_idx, int next_M,
                                                          double (*__restrict__ stats)[2]) {
@@ -392,15 +394,21 @@ __global__ __launch_bounds__(kThreads) void k_adam_chain(float* __restrict__ p, 
                 const int row = e / D, k = e - row * D;
                 w1op[((net * 2 + (row >> 5)) * 32 + (k >> 1)) * kWave + (row & 31) + 32 * (k & 1)] = pn;
             }
-            if (wop3) {      // k_mlp_step3's copies: the bf16 planes of the new value, W1 once, W2 forward and backward
+            if (wop3) {      // k_mlp_step3 / 4's copies: the bf16 planes of the new value wherever the weight appears as an operand
                 const int e2a = i - w2_actor, e2c = i - w2_critic;
                 const int e2 = (e2a >= 0 && e2a < H * H) ? e2a : ((e2c >= 0 && e2c < H * H) ? e2c : -1);
-                if (e >= 0 || e2 >= 0) {
-                    const bool is_w2 = e < 0;
-                    const int net = is_w2 ? ((e2a >= 0 && e2a < H * H) ? 0 : 1) : ((ea >= 0 && ea < H * D) ? 0 : 1);
-                    const int row = is_w2 ? e2 / H : e / D, col = is_w2 ? e2 % H : e - (e / D) * D;
+                const int e3a = i - w3_actor, e3c = i - w3_critic;
+                const int e3 = wop_mode != 4 ? -1 : ((e3a >= 0 && e3a < A * H) ? e3a : ((e3c >= 0 && e3c < H) ? e3c : -1));
+                if (e >= 0 || e2 >= 0 || e3 >= 0) {
+                    const int layer = e >= 0 ? 0 : (e2 >= 0 ? 1 : 2);
+                    const bool is_w2 = layer == 1;
+                    const int net = layer == 0 ? ((ea >= 0 && ea < H * D) ? 0 : 1)
+                                               : (layer == 1 ? ((e2a >= 0 && e2a < H * H) ? 0 : 1) : ((e3a >= 0 && e3a < A * H) ? 0 : 1));
+                    const int row = layer == 0 ? e / D : (layer == 1 ? e2 / H : e3 / H);
+                    const int col = layer == 0 ? e - (e / D) * D : (layer == 1 ? e2 % H : e3 % H);
                     int at[2];
-                    const int n_at = bf3::wop3_places(net, is_w2 ? 1 : 0, row, col, at);
+                    const int n_at = wop_mode == 4 ? bf3::wop4_places(net, layer, row, col, at)
+                                                   : bf3::wop3_places(net, is_w2 ? 1 : 0, row, col, at);
                     unsigned p0, p1, p2;
                     bf3::split3(pn, 0.0f, p0, p1, p2);
                     for (int q = 0; q < n_at; ++q) {
@@ -433,7 +441,8 @@ __global__ __launch_bounds__(kThreads) void k_adam_chain(float* __restrict__ p, 
 extern "C" size_t aurppo_mlp_workspace_bytes(int n_params) {
     return sizeof(double) * 2 * kStatBlocks + sizeof(double) * 8 * kMaxGrid + sizeof(float) * (size_t)kMaxGrid * (size_t)n_params + 64 +
            sizeof(unsigned long long) * 40 * kMaxGrid + sizeof(float) * 4 * 32 * 64 + 64 +
-           ((sizeof(double) * (size_t)((n_params + 63) / 64) + 63) / 64) * 64 + 64 + mlp_step3_wop_bytes() + 64;
+           ((sizeof(double) * (size_t)((n_params + 63) / 64) + 63) / 64) * 64 + 64 +
+           (mlp_step3_wop_bytes() > mlp_step4_wop_bytes() ? mlp_step3_wop_bytes() : mlp_step4_wop_bytes()) + 64;
 }
 
 namespace {
@@ -524,7 +533,8 @@ static int mlp_step_impl(const float* obs, const float* actions, const float* re
     const int sb = stat_blocks_for(M);
     a.n_stat_blocks = sb;
     const AurppoKnobs& knobs = aurppo_knobs();
-    const int variant = knobs.k7_variant == 3 ? 3 : 2;   // 2: k_mlp_step2 (f32 MFMA); 3: k_mlp_step3 (3 x bf16-split MFMA)
+    // 2: k_mlp_step2 (f32 MFMA); 3: k_mlp_step3 (3 x bf16-split MFMA, two tile sets); 4: k_mlp_step4 (the same arithmetic, transposed)
+    const int variant = (knobs.k7_variant == 3 || knobs.k7_variant == 4) ? knobs.k7_variant : 2;
     a.w1op = wv.w1op;
     a.tile_counter = wv.tile_counter;
     a.static_tiles = knobs.static_tiles ? 1 : 0;
@@ -534,8 +544,8 @@ static int mlp_step_impl(const float* obs, const float* actions, const float* re
         hipLaunchKernelGGL(k_adv_stats_idx, dim3(sb), dim3(kThreads), 0, s, a.rec, a.rec_stride, idx, M,
                            reinterpret_cast<double (*)[2]>(stats), params, a.L.w1[0], a.L.w1[1], D, a.w1op, a.tile_counter);
         AURPPO_LAUNCH_CHECK("k_adv_stats_idx");
-        if (variant == 3) {
-            const int rc = launch_mlp3_prep(params, a.L, D, wv.wop3, s);
+        if (variant >= 3) {
+            const int rc = variant == 3 ? launch_mlp3_prep(params, a.L, D, wv.wop3, s) : launch_mlp4_prep(params, a.L, D, A, wv.wop3, s);
             if (rc != AURPPO_OK) return rc;
         }
     }
@@ -556,10 +566,10 @@ static int mlp_step_impl(const float* obs, const float* actions, const float* re
     int grid = cus - spare;
     if (grid > kMaxGrid) grid = kMaxGrid;
     if (grid < 1) grid = 1;
-    if (grid > (n_tiles + 1) / 2) grid = (n_tiles + 1) / 2;     // two tile sets per workgroup
+    if (grid > (n_tiles + 1) / 2) grid = (n_tiles + 1) / 2;     // two tile sets (variant 4: two waves of each net) per workgroup
     if (ev_begin) AURPPO_HIP_TRY(hipEventRecord((hipEvent_t)ev_begin, s));
     {
-        const int rc = variant == 3 ? launch_mlp_step3(a, grid, s) : launch_mlp_step2(a, grid, s);
+        const int rc = variant == 4 ? launch_mlp_step4(a, grid, s) : (variant == 3 ? launch_mlp_step3(a, grid, s) : launch_mlp_step2(a, grid, s));
         if (rc != AURPPO_OK) return rc;
     }
     if (ev_end) AURPPO_HIP_TRY(hipEventRecord((hipEvent_t)ev_end, s));
@@ -575,8 +585,8 @@ static int mlp_step_impl(const float* obs, const float* actions, const float* re
         hipLaunchKernelGGL(k_adam_chain, dim3(nb_upd + nsb), dim3(kThreads), 0, s, chain->params_rw, grads, chain->exp_avg,
                            chain->exp_avg_sq, n_params, sq_part, n_red, (float)chain->max_norm, chain->lr_dev,
                            chain->step_dev, chain->beta1, chain->beta2, chain->eps, chain->out_norm, 1.0f, nb_upd, a.L.w1[0],
-                           a.L.w1[1], D, a.w1op, a.L.w2[0], a.L.w2[1], variant == 3 ? wv.wop3 : (unsigned short*)nullptr,
-                           a.rec, a.rec_stride, chain->next_idx, chain->next_M,
+                           a.L.w1[1], D, a.w1op, a.L.w2[0], a.L.w2[1], variant >= 3 ? wv.wop3 : (unsigned short*)nullptr,
+                           a.L.w3[0], a.L.w3[1], A, variant, a.rec, a.rec_stride, chain->next_idx, chain->next_M,
                            reinterpret_cast<double (*)[2]>(stats));
         AURPPO_LAUNCH_CHECK("k_adam_chain");
     }
@@ -607,8 +617,8 @@ int aurppo_mlp::launch_adam_tail(float* params, float* grads, float* exp_avg, fl
     // no operand-order copy of W1 (offsets past the bucket), no statistics for a next minibatch
     hipLaunchKernelGGL(k_adam_chain, dim3(nb_upd), dim3(kThreads), 0, s, params, grads, exp_avg, exp_avg_sq, n_params, sq_part,
                        (n_params + 63) / 64, (float)max_norm, lr_dev, step_dev, beta1, beta2, eps, out_norm, 1.0f, nb_upd, n_params,
-                       n_params, 1, (float*)nullptr, n_params, n_params, (unsigned short*)nullptr, (const float4*)nullptr, 1,
-                       (const int32_t*)nullptr, 0,
+                       n_params, 1, (float*)nullptr, n_params, n_params, (unsigned short*)nullptr, n_params, n_params, 1, 2,
+                       (const float4*)nullptr, 1, (const int32_t*)nullptr, 0,
                        (double (*)[2]) nullptr);
     AURPPO_LAUNCH_CHECK("k_adam_chain");
     return AURPPO_OK;
@@ -679,13 +689,17 @@ extern "C" int aurppo_mlp_ppo_apply_f32(float* params, float* grads, float* exp_
     const WsView wv = ws_view(workspace, n_params);
     double* stats = wv.stats;
     float* w1op = wv.w1op;
+    // the actor head's width from the layout: its bias follows its weight in the bucket (torch's parameter order)
+    int A_apply = (layout_h[5] - layout_h[4]) / H;
+    if (A_apply < 1 || A_apply > AP) A_apply = AP;
     int nb_upd = (n_params + kThreads * 4 - 1) / (kThreads * 4);
     if (nb_upd > 64) nb_upd = 64;
     const int nsb = next_idx ? stat_blocks_for(next_M) : 0;
     hipLaunchKernelGGL(k_adam_chain, dim3(nb_upd + nsb), dim3(kThreads), 0, (hipStream_t)stream, params, grads, exp_avg,
                        exp_avg_sq, n_params, (const double*)nullptr, 0, (float)max_norm, lr_dev, step_dev, beta1, beta2, eps,
                        out_norm, (float)grad_scale, nb_upd, layout_h[0], layout_h[6], D, w1op, layout_h[2], layout_h[8],
-                       aurppo_knobs().k7_variant == 3 ? wv.wop3 : (unsigned short*)nullptr,
+                       aurppo_knobs().k7_variant >= 3 ? wv.wop3 : (unsigned short*)nullptr, layout_h[4], layout_h[10], A_apply,
+                       aurppo_knobs().k7_variant,
                        reinterpret_cast<const float4*>(rec), rec_floats == 16 ? 4 : 1, next_idx, next_idx ? next_M : 0,
                        reinterpret_cast<double (*)[2]>(stats));
     AURPPO_LAUNCH_CHECK("k_adam_chain");
