@@ -27,6 +27,19 @@
 using namespace aurppo_mlp;
 using namespace bf3;
 
+// Diagnostic build only (tools/mlp_stamps.py): every wave accumulates the shader cycles of each stage of its tiles in
+// scalar registers; wave 0 of each workgroup dumps them to the workspace at the end.
+#ifdef AURPPO_MLP_STAMPS
+#define STAMP4(k)                                                         \
+    do {                                                                  \
+        const unsigned long long t__ = __builtin_readcyclecounter();      \
+        st_acc[k] += t__ - st_last;                                       \
+        st_last = t__;                                                    \
+    } while (0)
+#else
+#define STAMP4(k) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int kThreads4 = 256;
@@ -44,14 +57,70 @@ static_assert(kWaveBytes % 16 == 0 && oTab % 16 == 0, "alignment");
 constexpr int kPersist = 64 + 64 + 16 + 32 + 32 + 8 + 8;              // registers parked at the end: dW1, dW2, dW3, db1, db2, db3, dls
 static_assert(2 * kPersist * kWave * 4 <= oTab, "hand-over scratch must fit the dead images");
 
-__device__ __forceinline__ Frag3 w_frag(const bf16x8* wq, int id) {   // block `id` of this wave's net, this lane's 16 bytes per plane
+// block `id` of this wave's net: this lane's 16 bytes of each plane.  `wnet` is wave-uniform (scalar registers), `lane16` the
+// lane's byte offset: one scalar base per block + a 32-bit vector offset + an immediate per plane, instead of ninety 64-bit
+// vector addresses that would be formed once, hoisted out of the tile loop and spilled.
+__device__ __forceinline__ Frag3 w_frag(const char* wnet, int id, int lane16) {
+#ifdef AURPPO_V4_HACK_SAMEBLOCK      // timing experiment only (wrong results): every weight fragment from block 0, i.e. from L1
+    const char* blk = wnet + (id & 1) * (3 * 1024);
+#else
+    const char* blk = wnet + id * (3 * 1024);
+#endif
     Frag3 f;
-    f.p[0] = wq[(id * 3 + 0) * 64];
-    f.p[1] = wq[(id * 3 + 1) * 64];
-    f.p[2] = wq[(id * 3 + 2) * 64];
+    f.p[0] = *reinterpret_cast<const bf16x8*>(blk + lane16);
+    f.p[1] = *reinterpret_cast<const bf16x8*>(blk + 1024 + lane16);
+    f.p[2] = *reinterpret_cast<const bf16x8*>(blk + 2048 + lane16);
     return f;
 }
 
+// Epilogues of a 32-row accumulator block (my sample's 16 values of it), eight values = one B fragment at a time.
+// tanh(acc + bias) -> the two fragments
+__device__ __forceinline__ void tanh_frags(const f32x16& acc, const float* bt, Frag3& f0, Frag3& f1) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = tanh_fast(acc[e] + bt[e]);
+    f0 = regs_to_frag(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = tanh_fast(acc[8 + e] + bt[8 + e]);
+    f1 = regs_to_frag(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+}
+// dZ = dH (1 - h^2) with h read back from block b of its image (exact): the two B fragments of dZ (kappa order)
+__device__ __forceinline__ void dz_frags(const f32x16& dh, const char* img, int s, int h, int b, Frag3& f0, Frag3& f1) {
+    u32x2 q[4][3];
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+        const int o = xoff(s, 32 * b + 8 * gq + 4 * h);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) q[gq][p] = *reinterpret_cast<const u32x2*>(img + p * kXPlane + o);
+    }
+    unsigned w[3][8];
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+        const float h0 = join_lo(q[gq][0].x, q[gq][1].x, q[gq][2].x), h1 = join_hi(q[gq][0].x, q[gq][1].x, q[gq][2].x);
+        const float h2 = join_lo(q[gq][0].y, q[gq][1].y, q[gq][2].y), h3 = join_hi(q[gq][0].y, q[gq][1].y, q[gq][2].y);
+        const float d0 = dh[4 * gq + 0] * (1.0f - h0 * h0), d1 = dh[4 * gq + 1] * (1.0f - h1 * h1);
+        const float d2 = dh[4 * gq + 2] * (1.0f - h2 * h2), d3 = dh[4 * gq + 3] * (1.0f - h3 * h3);
+        split3(d0, d1, w[0][2 * gq], w[1][2 * gq], w[2][2 * gq]);
+        split3(d2, d3, w[0][2 * gq + 1], w[1][2 * gq + 1], w[2][2 * gq + 1]);
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        f0.p[p] = as_frag(w[p][0], w[p][1], w[p][2], w[p][3]);
+        f1.p[p] = as_frag(w[p][4], w[p][5], w[p][6], w[p][7]);
+    }
+}
+// acc += A . 1: the row sums of A (all 32 columns of the result are equal); bf16 1.0 = 0x3F80, planes 1 and 2 of "1" are zero
+__device__ __forceinline__ f32x16 mma_ones(const Frag3& a, f32x16 c) {
+    const bf16x8 one = as_frag(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[2], one, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[1], one, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], one, c, 0, 0, 0);
+    return c;
+}
+
+// FAST: state rows are 16-byte aligned multiples of four floats AND the records are packed (actions == nullptr): every row
+// fetch is a 16-byte load at (scalar base + 32-bit offset).  Otherwise the generic element-wise fetch.
+template <bool FAST>
 __global__ __launch_bounds__(kThreads4, 1) void k_mlp_step4(const MlpArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     __shared__ double s_red[2][kThreads4 / kWave];
@@ -61,7 +130,7 @@ __global__ __launch_bounds__(kThreads4, 1) void k_mlp_step4(const MlpArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int net = w >> 1, u = w & 1;            // waves 0,1: actor; 2,3: critic
-    const int s = lane & 31, h = lane >> 5;       // my sample of the tile; my half of every accumulator's rows
+    const int s0 = lane & 31, h0 = lane >> 5;     // my sample of the tile; my half of every accumulator's rows
     const int D = a.D, A = a.A;
     const int AW = a.continuous ? a.A : 1;
 
@@ -131,21 +200,20 @@ __global__ __launch_bounds__(kThreads4, 1) void k_mlp_step4(const MlpArgs a) {
     f32x4 gW3[4];                                 // rows = head outputs, columns 16 blk + (lane & 15)
 #pragma unroll
     for (int i = 0; i < 4; ++i) gW3[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float gb1[2][16], gb2[2][16], gb3[8], gls[8];  // per-lane partial sums over this lane's samples, accumulator order
-#pragma unroll
-    for (int e = 0; e < 16; ++e) gb1[0][e] = gb1[1][e] = gb2[0][e] = gb2[1][e] = 0.0f;
+    f32x16 gB1[2] = {zero16(), zero16()}, gB2[2] = {zero16(), zero16()};   // bias gradients as products with a column of ones (every column equal)
+    float gb3[8], gls[8];                          // head bias / log-std: per-lane partial sums over this lane's samples, accumulator order
 #pragma unroll
     for (int e = 0; e < 8; ++e) gb3[e] = gls[e] = 0.0f;
     double l0 = 0.0, l1 = 0.0, l2 = 0.0, l3 = 0.0, l4 = 0.0;    // actor: pg, ent, okl, kl, cf (lane half 0 counts); critic: vl in l0
 
-    const bf16x8* const wq = reinterpret_cast<const bf16x8*>(a.wop3) + (size_t)net * kW4Blocks * 3 * 64 + lane;
+    const char* const wnet0 = reinterpret_cast<const char*>(a.wop3) + (size_t)net * kW4Blocks * 3 * 1024;
     const int n_tiles = (a.h.M + R - 1) / R;
     unsigned* const ctr = a.tile_counter + net;
     const bool stat = a.static_tiles != 0;
     const int n_w = 2 * (int)gridDim.x, my_w = 2 * (int)blockIdx.x + u;     // waves that share this net's tiles
-    const bool vec4 = (D % 4 == 0) && ((reinterpret_cast<size_t>(a.obs) & 15) == 0);
     const bool packed = a.actions == nullptr;
-    const int nks1 = (D + 15) >> 4, ndb = (D + 31) >> 5;
+    // (FAST runs every k-step and both state blocks: beyond D the image and W1's copy are zero -- no branches in the chains)
+    const int nks1 = FAST ? 4 : (D + 15) >> 4, ndb = FAST ? 2 : (D + 31) >> 5;
 
     // ---- the tile queue of this wave: cur, nxt known; the grab for the one after is in flight
     int zero_off = 0;
@@ -170,7 +238,7 @@ __global__ __launch_bounds__(kThreads4, 1) void k_mlp_step4(const MlpArgs a) {
         t_nxt = t_cur + 1;
     }
     auto load_idx = [&](int tile) -> int {
-        const int m = tile * R + s;
+        const int m = tile * R + s0;
         const bool ok = tile < n_tiles && m < a.h.M;
         const int v = a.idx[ok ? m : 0];
         return ok ? v : -1;
@@ -181,49 +249,101 @@ __global__ __launch_bounds__(kThreads4, 1) void k_mlp_step4(const MlpArgs a) {
     float4 rc = make_float4(0.f, 0.f, 0.f, 0.f);
     float act[8];
     auto fetch = [&](int src) {
-        const size_t row = (size_t)(src >= 0 ? src : 0);
-        if (vec4) {
+        if (FAST) {
+            // scalar bases (kernel arguments) + 32-bit byte offsets: no 64-bit vector addresses to keep (and spill) across the loop
+            const unsigned row = (unsigned)(src >= 0 ? src : 0);
+            const char* const ob = reinterpret_cast<const char*>(a.obs);
+            const unsigned xo = row * (unsigned)(4 * D) + 32u * (unsigned)h0;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    const int c = 16 * ks + 8 * h + 4 * q;
-                    const float4 v = *reinterpret_cast<const float4*>(a.obs + (c < D ? row * D + c : (size_t)0));
+                    const int c = 16 * ks + 8 * h0 + 4 * q;
+                    const float4 v = *reinterpret_cast<const float4*>(ob + (c < D ? xo + 64u * ks + 16u * q : 0u));
                     xr[8 * ks + 4 * q + 0] = v.x; xr[8 * ks + 4 * q + 1] = v.y; xr[8 * ks + 4 * q + 2] = v.z; xr[8 * ks + 4 * q + 3] = v.w;
                 }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 32; ++e) {
-                const int c = 16 * (e >> 3) + 8 * h + (e & 7);
-                xr[e] = a.obs[c < D ? row * D + c : (size_t)0];
+            // the 64-byte record: {old_logp, adv, ret, old_v} + the action row: dims {0-3, 8-11} for lane half 0, {4-7} for half 1
+            const char* const rb = reinterpret_cast<const char*>(a.rec);
+            const unsigned ro = row * 64u;
+            rc = *reinterpret_cast<const float4*>(rb + ro);
+            if (net == 0) {
+                const float4 p = *reinterpret_cast<const float4*>(rb + ro + 16u + 16u * (unsigned)h0);
+                const float4 q = *reinterpret_cast<const float4*>(rb + ro + 48u);
+                // raw values only (touching a loaded value here would wait for it -- and for every older load -- on the spot): lane
+                // half 1's elements 4..7 stand for dims 12..15, which a packed record does not have and the loss masks (k >= A)
+                act[0] = p.x; act[1] = p.y; act[2] = p.z; act[3] = p.w;
+                act[4] = q.x; act[5] = q.y; act[6] = q.z; act[7] = q.w;
             }
+            return;
+        }
+        const size_t row = (size_t)(src >= 0 ? src : 0);
+#pragma unroll
+        for (int e = 0; e < 32; ++e) {
+            const int c = 16 * (e >> 3) + 8 * h0 + (e & 7);
+            xr[e] = a.obs[c < D ? row * D + c : (size_t)0];
         }
         rc = a.rec[row * a.rec_stride];
         if (net == 0) {
-            if (packed) {
-                // record floats 4.. hold the action row: dims {0-3, 8-11} for lane half 0, {4-7} for half 1 (12.. do not exist)
-                const float4* r4 = a.rec + row * 4;
-                const float4 p = r4[1 + h], q = r4[3 - 3 * h];            // half 0: floats 4-7 and 12-15; half 1: 8-11 (and the record again)
-                act[0] = p.x; act[1] = p.y; act[2] = p.z; act[3] = p.w;
-                act[4] = h ? 0.0f : q.x; act[5] = h ? 0.0f : q.y; act[6] = h ? 0.0f : q.z; act[7] = h ? 0.0f : q.w;
-            } else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int k = (e & 3) + 8 * (e >> 2) + 4 * h;
-                    act[e] = a.actions[k < AW ? row * AW + k : (size_t)0];
-                }
+            for (int e = 0; e < 8; ++e) {
+                const int k = (e & 3) + 8 * (e >> 2) + 4 * h0;
+                act[e] = packed ? (k < 12 && k < AW ? reinterpret_cast<const float*>(a.rec)[row * 16 + 4 + k] : 0.0f)
+                                : a.actions[k < AW ? row * AW + k : (size_t)0];
             }
         }
     };
     int src_cur = load_idx(t_cur);
     fetch(src_cur);
+    Frag3 wa[4], wb[4], wb2[4];                    // the weight stages (see the tile loop)
+    const char* wnet = wnet0;
+    int lane16 = lane * 16;
+    auto load4 = [&](Frag3 (&dst)[4], int id0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dst[q] = w_frag(wnet, id0 + q, lane16);
+    };
+    auto load2 = [&](Frag3 (&dst)[4], int id0) {
+        dst[0] = w_frag(wnet, id0, lane16);
+        dst[1] = w_frag(wnet, id0 + 1, lane16);
+    };
+    load4(wa, kW4_W1 + 0);
+#ifdef AURPPO_MLP_STAMPS
+    unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_readcyclecounter();
+    const unsigned long long clk0 = st_last, rt0 = wall_clock64();
+    unsigned long long n_my_tiles = 0;
+#endif
 
     while (t_cur < n_tiles) {
         // the tile after next: asked for now, read at the end of this tile
         if (!stat && lane == 0) t_raw = (int)atomicAdd(ctr + zero_off, 1u);
         const int src_nxt = load_idx(t_nxt);
         const bool real = src_cur >= 0;
+        // opaque per-tile copies of the lane coordinates: every LDS address below is re-derived from them inside the tile
+        // instead of being hoisted out of the loop as dozens of loop-invariant address registers that are then spilled
+        int s = s0, h = h0, lane_t = lane;
+        asm volatile("" : "+v"(s), "+v"(h), "+v"(lane_t));
+        {   // ... and of the weight base (scalar) and the lane's offset into a block
+            int wz = 0;                               // (an opaque zero added to the pointer keeps it a GLOBAL pointer)
+            asm volatile("" : "+s"(wz));
+            wnet = wnet0 + wz;
+            lane16 = lane_t * 16;
+        }
 
+        // Weight stages.  Every weight fragment is an L2 load; left to itself the scheduler hoists all 90 of a tile's to its
+        // top (they depend on nothing) and spills.  So the loads are issued by hand, one stage (4 k-steps of one block, 48
+        // registers) ahead of the chain that consumes them, into two buffers that alternate, with scheduling fences between
+        // the stages; inside a stage the order is "issue the next stage's loads, run this block's MFMA chain, finish the
+        // PREVIOUS block's epilogue under it".
+#define SB() __builtin_amdgcn_sched_barrier(0)
+        // Interleave hint for a region that holds an MFMA chain and an independent epilogue: n x {1 MFMA, nv VALU, nt TRANS}.  One
+        // wave per SIMD issues in order: vector work only overlaps the matrix pipe if it sits BETWEEN the MFMAs in program order,
+        // and left alone the scheduler emits the chain back to back and the epilogue behind it (profiles/r03: 30.7 k cycles per tile
+        // = the sum of the two).
+#define IL(n, nv, nt)                                              \
+        _Pragma("unroll") for (int i_ = 0; i_ < (n); ++i_) {      \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     \
+            __builtin_amdgcn_sched_group_barrier(0x002, nv, 0);    \
+            __builtin_amdgcn_sched_group_barrier(0x400, nt, 0);    \
+        }
         // ---- X: this lane's 32 observation elements -> B fragments (4 k-steps) + the [s][d] image dW1 reads
         Frag3 xb[4];
 #pragma unroll
@@ -242,48 +362,71 @@ __global__ __launch_bounds__(kThreads4, 1) void k_mlp_step4(const MlpArgs a) {
         float av[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) av[e] = act[e];
-
-        // ---- F1: Z1^T = W1 X^T, H1 = tanh(. + b1): two 32-row blocks; each becomes two B fragments and four image stores
-        Frag3 hb[4];                               // B fragments of the current layer's output, k-steps 0..3 (kappa order)
+        // ---- F1: Z1^T = W1 X^T (wa holds W1 block 0 since the end of the previous tile); k-step ks of the first block's chain only
+        // needs X's k-step ks: the chain runs under the rest of the split
+        Frag3 hb[4];                               // B fragments of H1, k-steps 0..3 (kappa order)
+        f32x16 acc0 = zero16(), acc1 = zero16();
+        load4(wb, kW4_W1 + 4);
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            f32x16 acc = zero16();
+        for (int ks = 0; ks < 4; ++ks)
+            if (ks < nks1) acc0 = mma32x3(wa[ks], xb[ks], acc0);
+        IL(24, 9, 0)
+        SB();
+        STAMP4(0);
+        load4(wa, kW4_W2 + 0);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                if (ks < nks1) acc = mma32x3(w_frag(wq, kW4_W1 + 4 * b + ks), xb[ks], acc);
-            const float* bt = sBt + (((net * 2 + 0) * 2 + b) * 2 + h) * 16;
-            float v[16];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) v[e] = tanh_fast(acc[e] + bt[e]);
-            hb[2 * b] = regs_to_frag(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
-            hb[2 * b + 1] = regs_to_frag(v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15]);
-            store_frags_x(sH1, s, h, b, hb[2 * b], hb[2 * b + 1]);
-        }
-        // ---- F2
+        for (int ks = 0; ks < 4; ++ks)
+            if (ks < nks1) acc1 = mma32x3(wb[ks], xb[ks], acc1);
+        tanh_frags(acc0, sBt + (((net * 2 + 0) * 2 + 0) * 2 + h) * 16, hb[0], hb[1]);
+        store_frags_x(sH1, s, h, 0, hb[0], hb[1]);
+        IL(24, 8, 2)
+        SB();
+        STAMP4(1);
+        // ---- F2 / F3, software-pipelined across the blocks: a chain's k-steps run as soon as the fragments they need exist, the
+        // tanh + split epilogue of one block under the MFMAs of the next
         Frag3 h2b[4];
-        float h2v[2][16];                          // H2 in fp32: dZ2 needs it right after the head
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            f32x16 acc = zero16();
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) acc = mma32x3(w_frag(wq, kW4_W2 + 4 * b + ks), hb[ks], acc);
-            const float* bt = sBt + (((net * 2 + 1) * 2 + b) * 2 + h) * 16;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) h2v[b][e] = tanh_fast(acc[e] + bt[e]);
-            h2b[2 * b] = regs_to_frag(h2v[b][0], h2v[b][1], h2v[b][2], h2v[b][3], h2v[b][4], h2v[b][5], h2v[b][6], h2v[b][7]);
-            h2b[2 * b + 1] = regs_to_frag(h2v[b][8], h2v[b][9], h2v[b][10], h2v[b][11], h2v[b][12], h2v[b][13], h2v[b][14], h2v[b][15]);
-            store_frags_x(sH2, s, h, b, h2b[2 * b], h2b[2 * b + 1]);
-        }
-        // ---- F3: head, rows 0..15 of a 32-row block (W3 zero-padded): registers 0..7 of this lane = its 8 head outputs
+        load4(wb, kW4_W2 + 4);
+        acc0 = zero16();
+        acc0 = mma32x3(wa[0], hb[0], acc0);
+        acc0 = mma32x3(wa[1], hb[1], acc0);
+        tanh_frags(acc1, sBt + (((net * 2 + 0) * 2 + 1) * 2 + h) * 16, hb[2], hb[3]);
+        store_frags_x(sH1, s, h, 1, hb[2], hb[3]);
+        f32x16 acc2 = zero16();
+        acc2 = mma32x3(wb[0], hb[0], acc2);
+        acc2 = mma32x3(wb[1], hb[1], acc2);
+        IL(24, 8, 2)
+        SB();
+        STAMP4(2);
+        acc0 = mma32x3(wa[2], hb[2], acc0);
+        acc0 = mma32x3(wa[3], hb[3], acc0);
+        load4(wa, kW4_W3);
+        acc2 = mma32x3(wb[2], hb[2], acc2);
+        acc2 = mma32x3(wb[3], hb[3], acc2);
+        tanh_frags(acc0, sBt + (((net * 2 + 1) * 2 + 0) * 2 + h) * 16, h2b[0], h2b[1]);
+        store_frags_x(sH2, s, h, 0, h2b[0], h2b[1]);
+        IL(12, 0, 0)
+        IL(12, 16, 3)
+        SB();
+        // ---- F3: head (W3 zero-padded to 32 rows)
+        load2(wb, kW4_W3T);
+        acc1 = zero16();
+        acc1 = mma32x3(wa[0], h2b[0], acc1);
+        acc1 = mma32x3(wa[1], h2b[1], acc1);
+        tanh_frags(acc2, sBt + (((net * 2 + 1) * 2 + 1) * 2 + h) * 16, h2b[2], h2b[3]);
+        store_frags_x(sH2, s, h, 1, h2b[2], h2b[3]);
+        IL(12, 16, 3)
+        SB();
+        acc1 = mma32x3(wa[2], h2b[2], acc1);
+        acc1 = mma32x3(wa[3], h2b[3], acc1);
         float outv[8];
         {
-            f32x16 acc = zero16();
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) acc = mma32x3(w_frag(wq, kW4_W3 + ks), h2b[ks], acc);
             const float* b3 = sB3t + (net * 2 + h) * 8;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) outv[e] = acc[e] + b3[e];
+            for (int e = 0; e < 8; ++e) outv[e] = acc1[e] + b3[e];
         }
+        SB();
+        STAMP4(3);
+        load4(wa, kW4_W2T + 0);                    // for dH1's first block, far ahead: the loss and dW3 / dW2 run meanwhile
         // ---- loss: this net's terms for my sample; head outputs become their gradients (per-lane code: the sample is the lane)
         float dv[8];
         if (net == 1) {
@@ -367,85 +510,105 @@ __global__ __launch_bounds__(kThreads4, 1) void k_mlp_step4(const MlpArgs a) {
                 const u32x4v q = __builtin_bit_cast(u32x4v, dob.p[p]);
                 *reinterpret_cast<u32x2*>(sDo + p * kDoPlane4 + s * kDoRow4 + 2 * (8 * gq + 4 * h)) = gq ? u32x2{q.z, q.w} : u32x2{q.x, q.y};
             }
-        // ---- dW3 += dOut^T H2: 16x16x32, one k-step over the 32 samples, both operands read across their images' rows
-        {
-            const Frag3 da = plain_cols16(sDo, kDoRow4, kDoPlane4, 0, lane);
-#pragma unroll
-            for (int blk = 0; blk < 4; ++blk) gW3[blk] = mma16x3(da, x_cols16(sH2, 16 * blk, lane), gW3[blk]);
-        }
-        // ---- dH2^T = W3^T dOut^T (K = 16), dZ2 = dH2 (1 - H2^2): B fragments for dH1 + image over H2's
+        SB();
+        STAMP4(4);
+        // ---- dH2^T = W3^T dOut^T (K = 16), then dW3 += dOut^T H2 (16x16x32, one k-step over the 32 samples, both operands read
+        // across their images' rows) with the dZ2 epilogues under its chains
         Frag3 dzb[4];
+        load4(wb2, kW4_W2T + 4);
+        acc0 = zero16();
+        acc1 = zero16();
+        acc0 = mma32x3(wb[0], dob, acc0);
+        acc1 = mma32x3(wb[1], dob, acc1);
+        {
+            const Frag3 da = plain_cols16(sDo, kDoRow4, kDoPlane4, 0, lane_t);
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            f32x16 acc = zero16();
-            acc = mma32x3(w_frag(wq, kW4_W3T + b), dob, acc);
-            float dz[16];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                dz[e] = acc[e] * (1.0f - h2v[b][e] * h2v[b][e]);
-                gb2[b][e] += dz[e];
-            }
-            dzb[2 * b] = regs_to_frag(dz[0], dz[1], dz[2], dz[3], dz[4], dz[5], dz[6], dz[7]);
-            dzb[2 * b + 1] = regs_to_frag(dz[8], dz[9], dz[10], dz[11], dz[12], dz[13], dz[14], dz[15]);
-            store_frags_x(sH2, s, h, b, dzb[2 * b], dzb[2 * b + 1]);
+            for (int blk = 0; blk < 4; ++blk) gW3[blk] = mma16x3(da, x_cols16(sH2, 16 * blk, lane_t), gW3[blk]);
         }
-        // ---- dW2 += dZ2^T H1
+        dz_frags(acc0, sH2, s, h, 0, dzb[0], dzb[1]);
+        dz_frags(acc1, sH2, s, h, 1, dzb[2], dzb[3]);
+        IL(12, 0, 0)
+        IL(24, 12, 0)
+        SB();       // (dW3 has read the H2 image: dZ2 may now take its place)
+        store_frags_x(sH2, s, h, 0, dzb[0], dzb[1]);
+        store_frags_x(sH2, s, h, 1, dzb[2], dzb[3]);
+        SB();
+        STAMP4(5);
+        // ---- dH1^T = W2^T dZ2^T (wa = W2^T block 0, loaded before the loss; wb2 = block 1, loaded before dH2), dZ1 kept as
+        // fragments: its image takes H1's place only after dW2 has read H1
+        acc0 = zero16();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) acc0 = mma32x3(wa[ks], dzb[ks], acc0);
+        acc1 = zero16();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) acc1 = mma32x3(wb2[ks], dzb[ks], acc1);
+        Frag3 d1b[4];
+        dz_frags(acc0, sH1, s, h, 0, d1b[0], d1b[1]);
+        IL(24, 0, 0)
+        IL(24, 8, 0)
+        SB();
+        STAMP4(6);
+        // ---- The long-latency loads of the tile go out HERE: the next tile's first weight stage, then its rows from HBM.  Returns
+        // are counted in issue order, so nothing issued after the row fetch can be used before it has come back: what follows
+        // until the next tile's X stage is LDS-and-matrix work only (dW2, dZ1's image, dW1: ~100 MFMAs).
+        load4(wa, kW4_W1 + 0);
+        fetch(src_nxt);
+        SB();
+        // ---- dW2 += dZ2^T H1;  db2 += dZ2^T 1 (the bias gradient as one more column of the product: accumulators stay in the
+        // matrix pipe's registers, no vector adds); dH1's second block gets its epilogue under these chains
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const Frag3 b0 = x_cols(sH1, ks, 0, lane), b1 = x_cols(sH1, ks, 32, lane);
+            const Frag3 b0 = x_cols(sH1, ks, 0, lane_t), b1 = x_cols(sH1, ks, 32, lane_t);
 #pragma unroll
             for (int ob = 0; ob < 2; ++ob) {
-                const Frag3 za = x_cols(sH2, ks, 32 * ob, lane);
+                const Frag3 za = x_cols(sH2, ks, 32 * ob, lane_t);
                 gW2[ob][0] = mma32x3(za, b0, gW2[ob][0]);
                 gW2[ob][1] = mma32x3(za, b1, gW2[ob][1]);
+                gB2[ob] = mma_ones(za, gB2[ob]);
             }
         }
-        // ---- dH1^T = W2^T dZ2^T, dZ1 = dH1 (1 - H1^2) (H1 back from its image: exact), image over H1's
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            f32x16 acc = zero16();
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) acc = mma32x3(w_frag(wq, kW4_W2T + 4 * b + ks), dzb[ks], acc);
-            Frag3 f0, f1;
-            float dz[16];
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const int o = xoff(s, 32 * b + 8 * gq + 4 * h);
-                const u32x2 q0 = *reinterpret_cast<const u32x2*>(sH1 + 0 * kXPlane + o);
-                const u32x2 q1 = *reinterpret_cast<const u32x2*>(sH1 + 1 * kXPlane + o);
-                const u32x2 q2 = *reinterpret_cast<const u32x2*>(sH1 + 2 * kXPlane + o);
-                const float h0 = join_lo(q0.x, q1.x, q2.x), h1 = join_hi(q0.x, q1.x, q2.x);
-                const float h2 = join_lo(q0.y, q1.y, q2.y), h3 = join_hi(q0.y, q1.y, q2.y);
-                dz[4 * gq + 0] = acc[4 * gq + 0] * (1.0f - h0 * h0);
-                dz[4 * gq + 1] = acc[4 * gq + 1] * (1.0f - h1 * h1);
-                dz[4 * gq + 2] = acc[4 * gq + 2] * (1.0f - h2 * h2);
-                dz[4 * gq + 3] = acc[4 * gq + 3] * (1.0f - h3 * h3);
-            }
-#pragma unroll
-            for (int e = 0; e < 16; ++e) gb1[b][e] += dz[e];
-            f0 = regs_to_frag(dz[0], dz[1], dz[2], dz[3], dz[4], dz[5], dz[6], dz[7]);
-            f1 = regs_to_frag(dz[8], dz[9], dz[10], dz[11], dz[12], dz[13], dz[14], dz[15]);
-            store_frags_x(sH1, s, h, b, f0, f1);
-        }
-        // ---- next tile's rows: issued here, behind everything that read xr / rec / act, ahead of the last chains
-        fetch(src_nxt);
-        // ---- dW1 += dZ1^T X
+        dz_frags(acc1, sH1, s, h, 1, d1b[2], d1b[3]);
+        IL(60, 4, 0)
+        SB();       // (dW2 has read the H1 image: dZ1 may now take its place)
+        store_frags_x(sH1, s, h, 0, d1b[0], d1b[1]);
+        store_frags_x(sH1, s, h, 1, d1b[2], d1b[3]);
+        SB();
+        STAMP4(7);
+        // ---- dW1 += dZ1^T X;  db1 += dZ1^T 1
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
+            const Frag3 z0 = x_cols(sH1, ks, 0, lane_t), z1 = x_cols(sH1, ks, 32, lane_t);
+            gB1[0] = mma_ones(z0, gB1[0]);
+            gB1[1] = mma_ones(z1, gB1[1]);
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
                 if (db < ndb) {
-                    const Frag3 xbq = x_cols(sX, ks, 32 * db, lane);
-#pragma unroll
-                    for (int ob = 0; ob < 2; ++ob) gW1[ob][db] = mma32x3(x_cols(sH1, ks, 32 * ob, lane), xbq, gW1[ob][db]);
+                    const Frag3 xbq = x_cols(sX, ks, 32 * db, lane_t);
+                    gW1[0][db] = mma32x3(z0, xbq, gW1[0][db]);
+                    gW1[1][db] = mma32x3(z1, xbq, gW1[1][db]);
                 }
             }
         }
+        SB();
+        STAMP4(8);
+#ifdef AURPPO_MLP_STAMPS
+        ++n_my_tiles;
+#endif
+#undef SB
+#undef IL
         // ---- advance the queue
         t_cur = t_nxt;
         src_cur = src_nxt;
         t_nxt = stat ? t_nxt + n_w : dyn_base + __builtin_amdgcn_readfirstlane(t_raw);
     }
+#ifdef AURPPO_MLP_STAMPS
+    if (w == 0 && lane == 0) {
+        for (int k = 0; k < 12; ++k) a.stamps[(size_t)blockIdx.x * 40 + k] = st_acc[k];
+        a.stamps[(size_t)blockIdx.x * 40 + 12] = n_my_tiles;
+        a.stamps[(size_t)blockIdx.x * 40 + 32] = __builtin_readcyclecounter() - clk0;
+        a.stamps[(size_t)blockIdx.x * 40 + 33] = wall_clock64() - rt0;
+    }
+#endif
     __syncthreads();      // every wave's images are dead: the hand-over below reuses them
 
     // ---- bias / log-std gradients: per-lane partials -> sums over the 32 lanes of each half
@@ -457,13 +620,6 @@ __global__ __launch_bounds__(kThreads4, 1) void k_mlp_step4(const MlpArgs a) {
         x += __shfl_xor(x, 16, kWave);
         return x;
     };
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            gb1[b][e] = half_sum(gb1[b][e]);
-            gb2[b][e] = half_sum(gb2[b][e]);
-        }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         gb3[e] = half_sum(gb3[e]);
@@ -498,8 +654,8 @@ __global__ __launch_bounds__(kThreads4, 1) void k_mlp_step4(const MlpArgs a) {
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                park[(144 + 16 * b + e) * kWave] = gb1[b][e];
-                park[(176 + 16 * b + e) * kWave] = gb2[b][e];
+                park[(144 + 16 * b + e) * kWave] = gB1[b][e];
+                park[(176 + 16 * b + e) * kWave] = gB2[b][e];
             }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -536,13 +692,13 @@ __global__ __launch_bounds__(kThreads4, 1) void k_mlp_step4(const MlpArgs a) {
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int o = 32 * b + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    slab[a.L.b1[net] + o] = gb1[b][e] + park[(144 + 16 * b + e) * kWave];
-                    slab[a.L.b2[net] + o] = gb2[b][e] + park[(176 + 16 * b + e) * kWave];
+                    const int o = 32 * b + (e & 3) + 8 * (e >> 2) + 4 * h0;
+                    slab[a.L.b1[net] + o] = gB1[b][e] + park[(144 + 16 * b + e) * kWave];
+                    slab[a.L.b2[net] + o] = gB2[b][e] + park[(176 + 16 * b + e) * kWave];
                 }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const int k = (e & 3) + 8 * (e >> 2) + 4 * h;
+                const int k = (e & 3) + 8 * (e >> 2) + 4 * h0;
                 if (k < od) slab[a.L.b3[net] + k] = gb3[e] + park[(208 + e) * kWave];
                 if (net == 0 && a.continuous && k < A) slab[a.L.logstd + k] = gls[e] + park[(216 + e) * kWave];
             }
@@ -614,11 +770,15 @@ int launch_mlp_step4(const MlpArgs& a, int grid, hipStream_t s) {
     static bool attr_set[kMaxDevices] = {false};
     const int dslot = aurppo_device_slot();
     if (!attr_set[dslot]) {
-        AURPPO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_step4), hipFuncAttributeMaxDynamicSharedMemorySize,
+        AURPPO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_step4<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)mlp_step4_lds_bytes()));
+        AURPPO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_step4<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)mlp_step4_lds_bytes()));
         attr_set[dslot] = true;
     }
-    hipLaunchKernelGGL(k_mlp_step4, dim3(grid), dim3(kThreads4), mlp_step4_lds_bytes(), s, a);
+    const bool fast = (a.D % 4 == 0) && ((reinterpret_cast<size_t>(a.obs) & 15) == 0) && a.actions == nullptr;
+    if (fast) hipLaunchKernelGGL(k_mlp_step4<true>, dim3(grid), dim3(kThreads4), mlp_step4_lds_bytes(), s, a);
+    else hipLaunchKernelGGL(k_mlp_step4<false>, dim3(grid), dim3(kThreads4), mlp_step4_lds_bytes(), s, a);
     AURPPO_LAUNCH_CHECK("k_mlp_step4");
     return AURPPO_OK;
 }

@@ -20,12 +20,26 @@ M = 131072
 idx = torch.randperm(obs.shape[0], device="cuda")[:M].int()
 lib = _lib.load()
 n = lay["n_params"]
+rec64 = Hh.pack_records(rec, act)        # the trainer's layout: record + action row in one 64-B line
 for _ in range(3):
-    Hh.mlp_ppo_step(obs, act, rec, idx, bucket.flat_param, lay, bucket.flat_grad, 0.2, 0.0, 0.5)
+    Hh.mlp_ppo_step(obs, None, rec64, idx, bucket.flat_param, lay, bucket.flat_grad, 0.2, 0.0, 0.5)
 torch.cuda.synchronize()
 ws = H._ws_cache[("mlp", torch.cuda.current_device())]
 off = ((8 * (2 * 256 + 8 * 256) + 4 * 256 * n + 63) // 64) * 64
-if True:
+if os.environ.get("AURPPO_K7_VARIANT") == "4":
+    raw = ws[off:off + 8 * 40 * 256].view(torch.int64).view(256, 40).cpu().numpy().astype(np.float64)
+    raw = raw[(raw[:, 12] > 0) & (raw[:, 12] < 100)]
+    cyc, ticks = np.median(raw[:, 32]), np.median(raw[:, 33])
+    print(f"k_mlp_step4, wave 0 of {raw.shape[0]} workgroups: tile loop {cyc:.0f} cycles in {ticks:.0f} ticks of the 100 MHz clock = {cyc / ticks * 0.1:.2f} GHz; "
+          f"{np.median(raw[:, 12]):.1f} tiles per wave (median)")
+    names = ["X split + image", "F1 (both blocks) + epilogue 0", "F2 + epilogue 1 of F1, 0 of F2", "F3 + epilogue 1 of F2", "loss + dOut",
+             "dH2, dW3, dZ2", "dH1 block 0, dW2", "dH1 block 1, dZ1", "fetch + dW1"]
+    per = raw[:, :9] / raw[:, 12:13]
+    med = np.median(per, axis=0)
+    for k, nm in enumerate(names):
+        print(f"   {nm:34s} {med[k]:9.0f} cycles per tile ({100 * med[k] / med.sum():5.1f} %)")
+    print(f"   {'total':34s} {med.sum():9.0f} cycles per tile")
+elif True:
     raw = ws[off:off + 8 * 40 * 256].view(torch.int64).view(256, 40).cpu().numpy().astype(np.float64)
     raw = raw[(raw[:, 1] > 0) & (raw[:, 35] > 0) & (raw[:, 35] < 1e6) & (raw[:, 36] > 0) & (raw[:, 36] < 1e7)]   # workgroups of this launch
     cyc, ticks = np.median(raw[:, 32]), np.median(raw[:, 33])
