@@ -440,7 +440,7 @@ __global__ __launch_bounds__(kThreads) void k_adam_chain(float* __restrict__ p, 
 
 extern "C" size_t aurppo_mlp_workspace_bytes(int n_params) {
     return sizeof(double) * 2 * kStatBlocks + sizeof(double) * 8 * kMaxGrid + sizeof(float) * (size_t)kMaxGrid * (size_t)n_params + 64 +
-           sizeof(unsigned long long) * 40 * kMaxGrid + sizeof(float) * 4 * 32 * 64 + 64 +
+           sizeof(unsigned long long) * 44 * kMaxGrid + sizeof(float) * 4 * 32 * 64 + 64 +
            ((sizeof(double) * (size_t)((n_params + 63) / 64) + 63) / 64) * 64 + 64 +
            (mlp_step3_wop_bytes() > mlp_step4_wop_bytes() ? mlp_step3_wop_bytes() : mlp_step4_wop_bytes()) + 64;
 }
@@ -478,7 +478,7 @@ WsView ws_view(void* workspace, int n_params) {
     v.slabs = reinterpret_cast<float*>(v.loss_part + 8 * kMaxGrid);
     v.stamps = reinterpret_cast<unsigned long long*>(w + ((sizeof(double) * (2 * kStatBlocks + 8 * kMaxGrid) +
                                                            sizeof(float) * (size_t)kMaxGrid * (size_t)n_params + 63) / 64) * 64);
-    v.w1op = reinterpret_cast<float*>(v.stamps + 40 * kMaxGrid);
+    v.w1op = reinterpret_cast<float*>(v.stamps + 44 * kMaxGrid);
     v.tile_counter = reinterpret_cast<unsigned*>(v.w1op + 4 * 32 * 64);
     v.sq_part = reinterpret_cast<double*>(v.tile_counter + 16);
     v.wop3 = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(v.sq_part) +

@@ -36,8 +36,16 @@ using namespace bf3;
             st_last = t__;                                                     \
         }                                                                      \
     } while (0)
+#define XSTAMP(k)                                                              \
+    do {                                                                       \
+        if (w == 0 && lane == 0) {                                             \
+            const unsigned long long t__ = __builtin_readcyclecounter();       \
+            s_xstamp[set][k] += t__ - st_last;                                 \
+        }                                                                      \
+    } while (0)
 #else
 #define STAMP3(k) do { } while (0)
+#define XSTAMP(k) do { } while (0)
 #endif
 
 namespace {
@@ -138,6 +146,7 @@ __global__ __launch_bounds__(kThreads3, 1) void k_mlp_step3(const MlpArgs a) {
     __shared__ int s_pbar[2][2];
 #ifdef AURPPO_MLP_STAMPS
     __shared__ unsigned long long s_stamp[2][16];
+    __shared__ unsigned long long s_xstamp[2][8];   // finer stamps inside F1 / B3 (diagnostic)
     unsigned long long st_last = 0;
     const unsigned long long rt_entry = wall_clock64();
 #endif
@@ -187,11 +196,17 @@ __global__ __launch_bounds__(kThreads3, 1) void k_mlp_step3(const MlpArgs a) {
     int grab_raw = 0;
 
     // ---- this wave's weight slices, streamed in operand order: 12 fragments of 16 B per lane and matrix
-    const bf16x8* const wop = reinterpret_cast<const bf16x8*>(a.wop3) + (size_t)wi * kWopMats * kWopKs * 3 * 64 + lane;
+    // (a wave-uniform base in scalar registers + the lane's 32-bit byte offset + an immediate per fragment: written as 36
+    // 64-bit vector addresses they were formed once, hoisted out of the tile loop, spilled, and every load then waited behind
+    // a scratch reload -- 3.5 k cycles per tile to ISSUE twelve loads; profiles/r03/k7_stamps_v3.txt)
+    const char* const wrole0 = reinterpret_cast<const char*>(a.wop3) + (size_t)wi * kWopMats * kWopKs * 3 * 1024;
+    const char* wrole = wrole0;
+    int lane16 = lane * 16;
     bf16x8 wreg[12];
     auto load_w = [&](int mt) {
+        const char* m = wrole + mt * (12 * 1024);
 #pragma unroll
-        for (int q = 0; q < 12; ++q) wreg[q] = wop[(mt * 12 + q) * 64];
+        for (int q = 0; q < 12; ++q) wreg[q] = *reinterpret_cast<const bf16x8*>(m + q * 1024 + lane16);
     };
 
     // ---- stage what stays in LDS for the whole launch: W3 images (both nets), biases, log-std
@@ -377,6 +392,7 @@ __global__ __launch_bounds__(kThreads3, 1) void k_mlp_step3(const MlpArgs a) {
     const int nks1 = (D + 15) >> 4;              // k-steps of layer 1 that hold anything (X and W1 are zero beyond D)
 #ifdef AURPPO_MLP_STAMPS
     if (tid < 32) (&s_stamp[0][0])[tid] = 0ull;
+    if (tid < 16) (&s_xstamp[0][0])[tid] = 0ull;
     __syncthreads();
     st_last = __builtin_readcyclecounter();
     const unsigned long long clk0 = st_last, rt0 = wall_clock64();
@@ -385,6 +401,12 @@ __global__ __launch_bounds__(kThreads3, 1) void k_mlp_step3(const MlpArgs a) {
     for (int it = 0; s_first[set] != 0; ++it) {
         int ln = lane, sl = st;
         asm volatile("" : "+v"(ln), "+v"(sl));    // opaque per-tile copies: LDS addresses are re-derived inside the phases
+        {
+            int wz = 0;                            // ... and the weight base (an opaque zero added to it keeps it a global pointer)
+            asm volatile("" : "+s"(wz));
+            wrole = wrole0 + wz;
+            lane16 = ln * 16;
+        }
         const int lr = sl >> 3, lj = sl & 7;
         {   // ---- S: land the prefetched tile as bf16 planes
             if (vec4) {
@@ -420,7 +442,9 @@ __global__ __launch_bounds__(kThreads3, 1) void k_mlp_step3(const MlpArgs a) {
             for (int ks = 0; ks < 4; ++ks)
                 if (ks < nks1) acc = mma32x3(x_rows(sX, ks, ln), wfrag(ks), acc);
             __builtin_amdgcn_sched_barrier(0);
+            XSTAMP(0);
             load_w(1);                                   // W2 (forward) arrives behind the epilogue and the barrier
+            XSTAMP(1);
             tanh_store(sH1, cb * 32, acc, sB1[net * H + cb * 32 + (ln & 31)], ln);
         }
         STAMP3(1);
@@ -559,7 +583,9 @@ __global__ __launch_bounds__(kThreads3, 1) void k_mlp_step3(const MlpArgs a) {
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+            XSTAMP(2);
             load_w(0);                                   // W1 slice for the next tile's F1
+            XSTAMP(3);
         }
         STAMP3(7);
         set_bar();
@@ -669,6 +695,10 @@ __global__ __launch_bounds__(kThreads3, 1) void k_mlp_step3(const MlpArgs a) {
     }
 #ifdef AURPPO_MLP_STAMPS
     if (tid < 32) a.stamps[(size_t)blockIdx.x * 40 + tid] = my_stamp;
+    if (tid < 1) {
+        a.stamps[(size_t)blockIdx.x * 40 + 39] = s_xstamp[0][0];
+    }
+    if (tid >= 64 && tid < 68) a.stamps[(size_t)256 * 40 + (size_t)blockIdx.x * 4 + (tid - 64)] = s_xstamp[0][tid - 64];
     if (tid == 0) {
         a.stamps[(size_t)blockIdx.x * 40 + 32] = __builtin_readcyclecounter() - clk0;
         a.stamps[(size_t)blockIdx.x * 40 + 33] = wall_clock64() - rt0;

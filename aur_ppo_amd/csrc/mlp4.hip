@@ -248,17 +248,17 @@ __global__ __launch_bounds__(kThreads4, 1) void k_mlp_step4(const MlpArgs a) {
     float xr[32];
     float4 rc = make_float4(0.f, 0.f, 0.f, 0.f);
     float act[8];
-    auto fetch = [&](int src) {
+    auto fetch = [&](int src, int hh) {     // hh = hh (an opaque copy inside the tile loop: nothing of this is to be hoisted)
         if (FAST) {
             // scalar bases (kernel arguments) + 32-bit byte offsets: no 64-bit vector addresses to keep (and spill) across the loop
             const unsigned row = (unsigned)(src >= 0 ? src : 0);
             const char* const ob = reinterpret_cast<const char*>(a.obs);
-            const unsigned xo = row * (unsigned)(4 * D) + 32u * (unsigned)h0;
+            const unsigned xo = row * (unsigned)(4 * D) + 32u * (unsigned)hh;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    const int c = 16 * ks + 8 * h0 + 4 * q;
+                    const int c = 16 * ks + 8 * hh + 4 * q;
                     const float4 v = *reinterpret_cast<const float4*>(ob + (c < D ? xo + 64u * ks + 16u * q : 0u));
                     xr[8 * ks + 4 * q + 0] = v.x; xr[8 * ks + 4 * q + 1] = v.y; xr[8 * ks + 4 * q + 2] = v.z; xr[8 * ks + 4 * q + 3] = v.w;
                 }
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(kThreads4, 1) void k_mlp_step4(const MlpArgs a) {
             const unsigned ro = row * 64u;
             rc = *reinterpret_cast<const float4*>(rb + ro);
             if (net == 0) {
-                const float4 p = *reinterpret_cast<const float4*>(rb + ro + 16u + 16u * (unsigned)h0);
+                const float4 p = *reinterpret_cast<const float4*>(rb + ro + 16u + 16u * (unsigned)hh);
                 const float4 q = *reinterpret_cast<const float4*>(rb + ro + 48u);
                 // raw values only (touching a loaded value here would wait for it -- and for every older load -- on the spot): lane
                 // half 1's elements 4..7 stand for dims 12..15, which a packed record does not have and the loss masks (k >= A)
@@ -279,21 +279,21 @@ __global__ __launch_bounds__(kThreads4, 1) void k_mlp_step4(const MlpArgs a) {
         const size_t row = (size_t)(src >= 0 ? src : 0);
 #pragma unroll
         for (int e = 0; e < 32; ++e) {
-            const int c = 16 * (e >> 3) + 8 * h0 + (e & 7);
+            const int c = 16 * (e >> 3) + 8 * hh + (e & 7);
             xr[e] = a.obs[c < D ? row * D + c : (size_t)0];
         }
         rc = a.rec[row * a.rec_stride];
         if (net == 0) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const int k = (e & 3) + 8 * (e >> 2) + 4 * h0;
+                const int k = (e & 3) + 8 * (e >> 2) + 4 * hh;
                 act[e] = packed ? (k < 12 && k < AW ? reinterpret_cast<const float*>(a.rec)[row * 16 + 4 + k] : 0.0f)
                                 : a.actions[k < AW ? row * AW + k : (size_t)0];
             }
         }
     };
     int src_cur = load_idx(t_cur);
-    fetch(src_cur);
+    fetch(src_cur, h0);
     Frag3 wa[4], wb[4], wb2[4];                    // the weight stages (see the tile loop)
     const char* wnet = wnet0;
     int lane16 = lane * 16;
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(kThreads4, 1) void k_mlp_step4(const MlpArgs a) {
         // are counted in issue order, so nothing issued after the row fetch can be used before it has come back: what follows
         // until the next tile's X stage is LDS-and-matrix work only (dW2, dZ1's image, dW1: ~100 MFMAs).
         load4(wa, kW4_W1 + 0);
-        fetch(src_nxt);
+        fetch(src_nxt, h);
         SB();
         // ---- dW2 += dZ2^T H1;  db2 += dZ2^T 1 (the bias gradient as one more column of the product: accumulators stay in the
         // matrix pipe's registers, no vector adds); dH1's second block gets its epilogue under these chains

@@ -40,6 +40,12 @@ if os.environ.get("AURPPO_K7_VARIANT") == "4":
         print(f"   {nm:34s} {med[k]:9.0f} cycles per tile ({100 * med[k] / med.sum():5.1f} %)")
     print(f"   {'total':34s} {med.sum():9.0f} cycles per tile")
 elif True:
+    if os.environ.get("AURPPO_K7_VARIANT") == "3":
+        x = ws[off + 8 * 40 * 256:off + 8 * 44 * 256].view(torch.int64).view(256, 4).cpu().numpy().astype(np.float64)
+        x = x[x[:, 0] > 0]
+        m = np.median(x, axis=0)
+        print(f"k_mlp_step3 set 0, cycles since the phase began (sum over tiles): F1 after the chain {m[0]:.0f}, after issuing W2's loads {m[1]:.0f}; "
+              f"B3 after the chain {m[2]:.0f}, after issuing W1's loads {m[3]:.0f}")
     raw = ws[off:off + 8 * 40 * 256].view(torch.int64).view(256, 40).cpu().numpy().astype(np.float64)
     raw = raw[(raw[:, 1] > 0) & (raw[:, 35] > 0) & (raw[:, 35] < 1e6) & (raw[:, 36] > 0) & (raw[:, 36] < 1e7)]   # workgroups of this launch
     cyc, ticks = np.median(raw[:, 32]), np.median(raw[:, 33])
