@@ -22,7 +22,7 @@ int env_int(const char* name, int dflt) {
 }
 AurppoKnobs parse_knobs() {
     AurppoKnobs k;
-    k.k7_variant = env_int("AURPPO_K7_VARIANT", 2);
+    k.k7_variant = env_int("AURPPO_K7_VARIANT", 3);   // default: k_mlp_step3 (see DESIGN 4.3d for the measurements behind it)
     k.k7_spare_cus = env_int("AURPPO_MLP_SPARE_CUS", 8);
     k.static_tiles = env_int("AURPPO_STATIC_TILES", 0);
     k.k2_one_stream = env_int("AURPPO_K2_ONE_STREAM", 0);

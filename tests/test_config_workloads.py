@@ -77,10 +77,11 @@ def test_first_block_at_config_minibatch_matches_torch_on_slices(T, N, C, S, M):
       * values against torch's direct fp32 convolution on 8 chunks of 64 samples taken across the batch;
       * gradients: the upstream gradient is zero outside those chunks, so the full-batch result must equal the SUM of the
         same kernel's results on the chunks alone (a per-sample kernel: same decisions, fixed-order sums) to rounding;
-      * each chunk's gradient against torch's on that chunk.  A weight-gradient element sums 64 x 16 x (S/2)^2 routed
-        products; where two elements of a pooling window (or a pre-activation and 0) are within an ulp the two
-        implementations may route differently, each such window moving an element by ~|gy * x| <= 1: 1e-3 of the
-        tensor's largest element (~600 at this size) covers it; the small shapes of tests/test_hip_parity.py hold 2e-5."""
+      * each chunk's gradient against torch's on that chunk, with the upstream gradient zeroed on the (handful of) pooling
+        windows whose two largest pre-pool candidates -- or whose winner and the ReLU threshold -- are within 1e-5 of each
+        other: there two correct fp32 implementations may route the gradient to different positions (each such window
+        moves a weight-gradient element by up to |gy * x| ~ 4, against 2e-5 x 600 for rounding), everywhere else they must
+        agree to the tolerance the small shapes of tests/test_hip_parity.py hold."""
     import torch.nn.functional as F
     from aur_ppo_amd import hip_ops as H
     g = torch.Generator(device="cuda").manual_seed(M)
@@ -106,12 +107,22 @@ def test_first_block_at_config_minibatch_matches_torch_on_slices(T, N, C, S, M):
             sum_b += bk.grad
             w1, b1 = w.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
             x = torch.cat([obs[lo:hi], state[lo:hi].view(-1, 1, 1, 1).expand(hi - lo, 1, S, S)], 1)
-            ref = F.max_pool2d(F.relu(F.conv2d(x, w1, b1, padding=1)), 2)
+            z = F.conv2d(x, w1, b1, padding=1)
+            ref = F.max_pool2d(F.relu(z), 2)
             torch.testing.assert_close(y[lo:hi], ref, rtol=1e-5, atol=2e-6)
-            (ref * gy[lo:hi]).sum().backward()
+            with torch.no_grad():        # windows without a clear winner
+                So = S // 2
+                win = z[:, :, :2 * So, :2 * So].reshape(hi - lo, 16, So, 2, So, 2).permute(0, 1, 2, 4, 3, 5).reshape(hi - lo, 16, So, So, 4)
+                top = win.topk(2, dim=-1).values
+                clear = ((top[..., 0] - top[..., 1]) > 1e-5 * top[..., 0].abs().clamp(min=1.0)) & (top[..., 0].abs() > 1e-5)
+                gm = gy[lo:hi] * clear
+            (ref * gm).sum().backward()
+            wk2, bk2 = w.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+            (H.first_block(obs[lo:hi].contiguous(), state[lo:hi].contiguous(), wk2, bk2) * gm).sum().backward()
+            assert float((~clear).float().mean()) < 1e-4                      # a handful per chunk, not a loophole
             sw, sb = float(w1.grad.abs().max()), float(b1.grad.abs().max())
-            assert float((wk.grad - w1.grad).abs().max()) <= 1e-3 * sw, (float((wk.grad - w1.grad).abs().max()), sw)
-            assert float((bk.grad - b1.grad).abs().max()) <= 1e-3 * sb, (float((bk.grad - b1.grad).abs().max()), sb)
+            assert float((wk2.grad - w1.grad).abs().max()) <= 2e-5 * sw + 1e-6, (float((wk2.grad - w1.grad).abs().max()), sw)
+            assert float((bk2.grad - b1.grad).abs().max()) <= 2e-5 * sb + 1e-6, (float((bk2.grad - b1.grad).abs().max()), sb)
     sw, sb = float(sum_w.abs().max()), float(sum_b.abs().max())
     assert float((w.grad - sum_w).abs().max()) <= 2e-5 * sw + 1e-6, (float((w.grad - sum_w).abs().max()), sw)
     assert float((b.grad - sum_b).abs().max()) <= 2e-5 * sb + 1e-6, (float((b.grad - sum_b).abs().max()), sb)
