@@ -28,6 +28,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+os.environ.setdefault("AURPPO_TEST_KNOBS", "1")   # the library re-reads AURPPO_K7_VARIANT per call: the plain-fp32 K7 is timed beside the default one
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
@@ -519,7 +521,26 @@ def main():
                     "how": f"hipEvent pair recorded inside the library around the K7 kernel, one extra stand-alone "
                            f"launch every {run['every']}th step on the update's own minibatch"
                            + (" (the update itself is a hipGraph)" if agent._graph is not None else "")}
-        if k7_variant == 3 and not agent._mlp.get("wide"):
+        if k7_variant != 2 and not agent._mlp.get("wide"):
+            # the plain-fp32 number beside it: the same minibatch through k_mlp_step2 (v_mfma_f32_32x32x2_f32), stand-alone launches
+            prev = os.environ.get("AURPPO_K7_VARIANT")
+            os.environ["AURPPO_K7_VARIANT"] = "2"
+            try:
+                evs = []
+                for _ in range(6):
+                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    agent.probe_mlp_step(ev)
+                    evs.append(ev)
+                torch.cuda.synchronize()
+                ms2 = float(np.mean([b.elapsed_time(e) for b, e in evs[1:]]))
+                roofline["plain_f32_mfma"] = {"kernel": "k_mlp_step2 (v_mfma_f32_32x32x2_f32, fp32 operands)", "avg_launch_us": round(ms2 * 1e3, 2),
+                                              "achieved": round(flops / (ms2 * 1e-3) / 1e12, 2), "frac": round(flops / (ms2 * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                                              "how": "5 stand-alone launches on the same minibatch after the timed region (AURPPO_K7_VARIANT=2)"}
+            finally:
+                if prev is None:
+                    os.environ.pop("AURPPO_K7_VARIANT", None)
+                else:
+                    os.environ["AURPPO_K7_VARIANT"] = prev
             roofline["arithmetic"] = ("fp32 operands as three bf16 planes each, six v_mfma_f32_32x32x16_bf16 products per "
                                       "K = 16 (dropped terms <= 2^-24 relative), fp32 accumulate; `peak` stays the fp32 MFMA "
                                       "peak the same FLOPs would be priced at on v_mfma_f32_32x32x2_f32")
