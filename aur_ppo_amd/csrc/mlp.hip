@@ -566,6 +566,10 @@ static int mlp_step_impl(const float* obs, const float* actions, const float* re
     int grid = cus - spare;
     if (grid > kMaxGrid) grid = kMaxGrid;
     if (grid < 1) grid = 1;
+    // A minibatch that every CU could take in ONE round of tiles (two per workgroup) but the spare-CU grid could not -- BASELINE
+    // config 4's shard, 512 envs x 128 steps / 4 = 512 tiles against 2 x 248 -- gets all the CUs: the stragglers' second round
+    // was a quarter of that launch (stamps at M = 16 384: tile loop 12.0 us median, 22.2 us for the sets that drew a second tile)
+    if (n_tiles > 2 * grid && n_tiles <= 2 * cus && cus <= kMaxGrid) grid = cus;
     if (grid > (n_tiles + 1) / 2) grid = (n_tiles + 1) / 2;     // two tile sets (variant 4: two waves of each net) per workgroup
     if (ev_begin) AURPPO_HIP_TRY(hipEventRecord((hipEvent_t)ev_begin, s));
     {

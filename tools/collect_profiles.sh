@@ -4,7 +4,9 @@
 #   bench_under_rocprof.json + bench_kernel_stats.csv            the same command under rocprofv3 --kernel-trace --stats
 #   bench_nofused_*.json/csv            bench.py --no-fused-mlp (per-op path: K1, K3, K4+K5, K6b stand-alone durations)
 #   bench_forcedp_*.json/csv            bench.py --force-dp (the W > 1 launch path captured around a one-rank RCCL all-reduce)
-#   mlp_pmc.json                        separate --pmc passes for the K7 kernel's HBM traffic
+#   mlp3_pmc.json                       separate --pmc passes for the default K7 kernel's (k_mlp_step3) HBM traffic; mlp_pmc.json: k_mlp_step2's
+#   k7_stamps_v{2,3,4}.txt              in-kernel phase stamps of the three K7 builds (tools/mlp_stamps.py); k7_time.txt: stand-alone launch times
+#   k2_stamps.txt, k2_time.txt          accept-kernel stamps and the shuffle pipeline's stand-alone time for both accept kernels
 #   bench_wide_{3x128,3x64,2x128}*.json/csv   bench.py --hidden-dim/--num-layers (K7w / K8w), plain and under rocprofv3
 #   wide_bench.json                     tools/bench_wide.py: K7w / K8w against the per-op path over the -d / -nl shapes
 # Each step runs under its own timeout; a step that times out stops the script (no GPU step after a hang).
@@ -38,30 +40,19 @@ for shape in "128 3" "64 3" "128 2"; do
   run 600 python3 $R/bench.py --hidden-dim $1 --num-layers $2 --steps 30 --cpu-baseline-updates 1 > $O/bench_wide_$2x$1.json 2> $O/bench_wide_$2x$1.err
 done
 run 600 python3 $R/tools/bench_wide.py > $O/wide_bench.json 2> $O/wide_bench.err
-run 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 2 --warmup 2 --no-probe --cpu-baseline-updates 0 > /dev/null 2>&1
-run 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 2 --warmup 2 --no-probe --cpu-baseline-updates 0 > /dev/null 2>&1
+for v in 2 3 4; do AURPPO_K7_VARIANT=$v run 300 python3 $R/tools/mlp_stamps.py > $O/k7_stamps_v$v.txt 2>&1; done
+(for m in 131072 16384; do for v in 3 2 4; do K7_M=$m AURPPO_K7_VARIANT=$v python3 $R/tools/k7_time.py 2>&1 | tail -1; done; done) > $O/k7_time.txt
+(for a in 1 2; do AURPPO_K2_ACCEPT=$a python3 $R/tools/k2_time.py 2>&1 | tail -1; done) > $O/k2_time.txt
+(AURPPO_K2_ACCEPT=1 python3 $R/tools/accept_stamps.py 2>&1 | tail -10; AURPPO_K2_ACCEPT=2 python3 $R/tools/accept_stamps.py 2>&1 | tail -8) > $O/k2_stamps.txt
+cd /tmp
+pmc() {  # pmc <variant> <kernel> <out>
+  rm -rf $O/pmc_fetch $O/pmc_write
+  AURPPO_K7_VARIANT=$1 run 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 2 --warmup 2 --no-probe --cpu-baseline-updates 0 --no-parity --shard-envs-per-gpu 0 > /dev/null 2>&1
+  AURPPO_K7_VARIANT=$1 run 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 2 --warmup 2 --no-probe --cpu-baseline-updates 0 --no-parity --shard-envs-per-gpu 0 > /dev/null 2>&1
+  python3 $R/tools/parse_pmc.py $2 $O/$3 $O/pmc_fetch $O/pmc_write
+  rm -rf $O/pmc_fetch $O/pmc_write
+}
+pmc 3 k_mlp_step3 mlp3_pmc.json
+pmc 2 k_mlp_step2 mlp_pmc.json
 cd $R
-python3 - <<PY
-import csv, glob, json
-vals = {}
-for d in ("$O/pmc_fetch", "$O/pmc_write"):
-    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
-        for r in csv.DictReader(open(f)):
-            if "k_mlp_step2" in r["Kernel_Name"]:
-                vals.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-fetch = sum(vals["FETCH_SIZE"]) / len(vals["FETCH_SIZE"]) * 1024
-write = sum(vals["WRITE_SIZE"]) / len(vals["WRITE_SIZE"]) * 1024
-M = 131072
-alg = M * 300           # observation row 256 B + action row 24 B + record 16 B + index 4 B
-res = {"kernel": "k_mlp_step2", "launches": {k: len(v) for k, v in vals.items()},
-       "fetch_size_raw_bytes": fetch, "write_size_bytes": write,
-       "fetch_corrected_bytes": 2 * fetch, "hbm_bytes_per_launch": 2 * fetch + write,
-       "algorithmic_read_bytes": alg,
-       "algorithmic_note": "obs 256 B + action 24 B + record 16 B + idx 4 B per sample, read once; writes = gradient slabs (one per workgroup)",
-       "correction": "FETCH_SIZE x2 (MI355X_MICROARCH.md section HBM: gfx950 tallies a 128-B memory-side request at 64 B); WRITE_SIZE exact. Every random access moves whole 128-B lines: observation row 2 lines + packed 64-B record (record and action row) 1 line = 384 B per sample against 300 B algorithmic",
-       "collected": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of bench.py --steps 2 --warmup 2 --no-probe; mean over the launches; counters in KiB"}
-json.dump(res, open("$O/mlp_pmc.json", "w"), indent=1)
-print(json.dumps(res))
-PY
-rm -rf $O/pmc_fetch $O/pmc_write
 ls -la $O

@@ -16,7 +16,7 @@ _lib._lib = None
 from tests.test_mlp_fused import _setup
 Hh, pol, bucket, obs, act, rec = _setup(128, 4096, 64, 6)
 lay = Hh.mlp_layout(pol, bucket)
-M = 131072
+M = int(os.environ.get("K7_M", 131072))
 idx = torch.randperm(obs.shape[0], device="cuda")[:M].int()
 lib = _lib.load()
 n = lay["n_params"]
