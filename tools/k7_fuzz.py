@@ -17,7 +17,7 @@ for case in range(n_cases):
     B = T * N
     M = random.choice([1, 2, 31, 32, 33, 63, 64, 65, 100, 255, 256, 257, 1000, B // 4, B // 2, B])
     M = max(1, min(M, B))
-    os.environ["AURPPO_MLP_VARIANT"] = random.choice(["1", "2", "2", "2"])
+    os.environ["AURPPO_K7_VARIANT"] = random.choice(["2", "3", "3", "4"])
     norm_adv = random.random() < 0.7 and M > 1
     vmode = random.choice([0, 1, 2])
     packed = (A if cont else 1) <= 12 and random.random() < 0.5
@@ -61,7 +61,7 @@ for case in range(n_cases):
             k = p_.numel()
             print(f"   {nm:14s} max |err| {float((g[off:off + k] - g_ref[off:off + k]).abs().max()):.3e}  max |ref| {float(g_ref[off:off + k].abs().max()):.3e}")
             off += k
-        print("   variant", os.environ["AURPPO_MLP_VARIANT"], "packed", packed, "T,N", T, N)
+        print("   variant", os.environ["AURPPO_K7_VARIANT"], "packed", packed, "T,N", T, N)
     assert err < 1e-4, (case, cont, D, A, M, norm_adv, vmode, err)
     worst = max(worst, err)
     assert torch.allclose(sc, sc_ref, rtol=5e-5, atol=5e-6, equal_nan=True), (case, sc, sc_ref)
