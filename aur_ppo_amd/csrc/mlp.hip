@@ -309,6 +309,50 @@ __global__ __launch_bounds__(1024) void k_mlp_reduce(const float* __restrict__ s
     }
 }
 
+// Where an updated weight is also kept in MFMA-operand order for the next K7 launch (W1 in k_mlp_step2's fp32 B-operand order;
+// W1 / W2 (/ W3) as bf16 planes for k_mlp_step3 / 4).  Offsets past the bucket switch a copy off.
+struct OperandCopies {
+    int w1_actor, w1_critic, D;
+    float* w1op;
+    int w2_actor, w2_critic;
+    unsigned short* wop3;
+    int w3_actor, w3_critic, A, wop_mode;
+};
+__device__ __forceinline__ void refresh_operand_copies(const OperandCopies& oc, int i, float pn) {
+    const int D = oc.D, A = oc.A;
+    const int ea = i - oc.w1_actor, ec = i - oc.w1_critic;
+    const int e = (ea >= 0 && ea < H * D) ? ea : ((ec >= 0 && ec < H * D) ? ec : -1);
+    if (e >= 0 && oc.w1op) {
+        const int net = (ea >= 0 && ea < H * D) ? 0 : 1;
+        const int row = e / D, k = e - row * D;
+        oc.w1op[((net * 2 + (row >> 5)) * 32 + (k >> 1)) * kWave + (row & 31) + 32 * (k & 1)] = pn;
+    }
+    if (oc.wop3) {      // k_mlp_step3 / 4's copies: the bf16 planes of the new value wherever the weight appears as an operand
+        const int e2a = i - oc.w2_actor, e2c = i - oc.w2_critic;
+        const int e2 = (e2a >= 0 && e2a < H * H) ? e2a : ((e2c >= 0 && e2c < H * H) ? e2c : -1);
+        const int e3a = i - oc.w3_actor, e3c = i - oc.w3_critic;
+        const int e3 = oc.wop_mode != 4 ? -1 : ((e3a >= 0 && e3a < A * H) ? e3a : ((e3c >= 0 && e3c < H) ? e3c : -1));
+        if (e >= 0 || e2 >= 0 || e3 >= 0) {
+            const int layer = e >= 0 ? 0 : (e2 >= 0 ? 1 : 2);
+            const bool is_w2 = layer == 1;
+            const int net = layer == 0 ? ((ea >= 0 && ea < H * D) ? 0 : 1)
+                                       : (layer == 1 ? ((e2a >= 0 && e2a < H * H) ? 0 : 1) : ((e3a >= 0 && e3a < A * H) ? 0 : 1));
+            const int row = layer == 0 ? e / D : (layer == 1 ? e2 / H : e3 / H);
+            const int col = layer == 0 ? e - (e / D) * D : (layer == 1 ? e2 % H : e3 % H);
+            int at[2];
+            const int n_at = oc.wop_mode == 4 ? bf3::wop4_places(net, layer, row, col, at)
+                                              : bf3::wop3_places(net, is_w2 ? 1 : 0, row, col, at);
+            unsigned p0, p1, p2;
+            bf3::split3(pn, 0.0f, p0, p1, p2);
+            for (int q = 0; q < n_at; ++q) {
+                oc.wop3[at[q]] = (unsigned short)p0;
+                oc.wop3[at[q] + bf3::kWopBlock] = (unsigned short)p1;
+                oc.wop3[at[q] + 2 * bf3::kWopBlock] = (unsigned short)p2;
+            }
+        }
+    }
+}
+
 // Chained minibatch step, third launch: global-norm clip + Adam over the bucket (K6b's arithmetic); the W1
 // elements it has just updated are dropped into the operand-order copy the next K7 launch streams; and the
 // workgroups past `nb_upd` form the next minibatch's advantage partial sums -- so nothing is left to prepare
@@ -318,10 +362,7 @@ __global__ __launch_bounds__(kThreads) void k_adam_chain(float* __restrict__ p, 
                                                          int n_part, float max_norm, const float* __restrict__ lr_dev,
                                                          const float* __restrict__ step, double beta1, double beta2,
                                                          double eps, float* __restrict__ out_norm, float gscale, int nb_upd,
-                                                         int w1_actor, int w1_critic, int D, float* __restrict__ w1op,
-                                                         int w2_actor, int w2_critic, unsigned short* __restrict__ wop3,
-                                                         int w3_actor, int w3_critic, int A, int wop_mode,
-                                                         const float4* __restrict__ rec, int rec_stride,
+                                                         OperandCopies oc, const float4* __restrict__ rec, int rec_stride,
                                                          const int32_t* __restrict__ next_idx, int next_M,
                                                          double (*__restrict__ stats)[2]) {
     __shared__ double sc[2][kThreads / kWave];
@@ -387,37 +428,7 @@ __global__ __launch_bounds__(kThreads) void k_adam_chain(float* __restrict__ p, 
             } else {
                 pn = adam_update(p, g, m, v, i, true, a, part != nullptr);
             }
-            const int ea = i - w1_actor, ec = i - w1_critic;
-            const int e = (ea >= 0 && ea < H * D) ? ea : ((ec >= 0 && ec < H * D) ? ec : -1);
-            if (e >= 0 && w1op) {
-                const int net = (ea >= 0 && ea < H * D) ? 0 : 1;
-                const int row = e / D, k = e - row * D;
-                w1op[((net * 2 + (row >> 5)) * 32 + (k >> 1)) * kWave + (row & 31) + 32 * (k & 1)] = pn;
-            }
-            if (wop3) {      // k_mlp_step3 / 4's copies: the bf16 planes of the new value wherever the weight appears as an operand
-                const int e2a = i - w2_actor, e2c = i - w2_critic;
-                const int e2 = (e2a >= 0 && e2a < H * H) ? e2a : ((e2c >= 0 && e2c < H * H) ? e2c : -1);
-                const int e3a = i - w3_actor, e3c = i - w3_critic;
-                const int e3 = wop_mode != 4 ? -1 : ((e3a >= 0 && e3a < A * H) ? e3a : ((e3c >= 0 && e3c < H) ? e3c : -1));
-                if (e >= 0 || e2 >= 0 || e3 >= 0) {
-                    const int layer = e >= 0 ? 0 : (e2 >= 0 ? 1 : 2);
-                    const bool is_w2 = layer == 1;
-                    const int net = layer == 0 ? ((ea >= 0 && ea < H * D) ? 0 : 1)
-                                               : (layer == 1 ? ((e2a >= 0 && e2a < H * H) ? 0 : 1) : ((e3a >= 0 && e3a < A * H) ? 0 : 1));
-                    const int row = layer == 0 ? e / D : (layer == 1 ? e2 / H : e3 / H);
-                    const int col = layer == 0 ? e - (e / D) * D : (layer == 1 ? e2 % H : e3 % H);
-                    int at[2];
-                    const int n_at = wop_mode == 4 ? bf3::wop4_places(net, layer, row, col, at)
-                                                   : bf3::wop3_places(net, is_w2 ? 1 : 0, row, col, at);
-                    unsigned p0, p1, p2;
-                    bf3::split3(pn, 0.0f, p0, p1, p2);
-                    for (int q = 0; q < n_at; ++q) {
-                        wop3[at[q]] = (unsigned short)p0;
-                        wop3[at[q] + bf3::kWopBlock] = (unsigned short)p1;
-                        wop3[at[q] + 2 * bf3::kWopBlock] = (unsigned short)p2;
-                    }
-                }
-            }
+            refresh_operand_copies(oc, i, pn);
         }
     } else {
         const int nsb = gridDim.x - nb_upd, b = blockIdx.x - nb_upd;
@@ -586,16 +597,23 @@ static int mlp_step_impl(const float* obs, const float* actions, const float* re
         int nb_upd = (n_params + kThreads * 4 - 1) / (kThreads * 4);
         if (nb_upd > 64) nb_upd = 64;
         const int nsb = chain->next_idx ? stat_blocks_for(chain->next_M) : 0;
+        const OperandCopies oc = {a.L.w1[0], a.L.w1[1], D, a.w1op, a.L.w2[0], a.L.w2[1],
+                                  variant >= 3 ? wv.wop3 : (unsigned short*)nullptr, a.L.w3[0], a.L.w3[1], A, variant};
         hipLaunchKernelGGL(k_adam_chain, dim3(nb_upd + nsb), dim3(kThreads), 0, s, chain->params_rw, grads, chain->exp_avg,
                            chain->exp_avg_sq, n_params, sq_part, n_red, (float)chain->max_norm, chain->lr_dev,
-                           chain->step_dev, chain->beta1, chain->beta2, chain->eps, chain->out_norm, 1.0f, nb_upd, a.L.w1[0],
-                           a.L.w1[1], D, a.w1op, a.L.w2[0], a.L.w2[1], variant >= 3 ? wv.wop3 : (unsigned short*)nullptr,
-                           a.L.w3[0], a.L.w3[1], A, variant, a.rec, a.rec_stride, chain->next_idx, chain->next_M,
-                           reinterpret_cast<double (*)[2]>(stats));
+                           chain->step_dev, chain->beta1, chain->beta2, chain->eps, chain->out_norm, 1.0f, nb_upd, oc,
+                           a.rec, a.rec_stride, chain->next_idx, chain->next_M, reinterpret_cast<double (*)[2]>(stats));
         AURPPO_LAUNCH_CHECK("k_adam_chain");
     }
     return AURPPO_OK;
 }
+
+namespace {
+OperandCopies no_operand_copies(int n_params) {   // every offset past the bucket: no copy is refreshed
+    const OperandCopies oc = {n_params, n_params, 1, nullptr, n_params, n_params, nullptr, n_params, n_params, 1, 2};
+    return oc;
+}
+}  // namespace
 
 int aurppo_mlp::launch_mlp_reduce(const float* slabs, const double* loss_part, int n_slabs, int n_params, const PpoHyper& h,
                                   float* grads, float* out_scalars, hipStream_t s, double* sq_part, float* step_dev,
@@ -620,9 +638,8 @@ int aurppo_mlp::launch_adam_tail(float* params, float* grads, float* exp_avg, fl
     if (nb_upd > 64) nb_upd = 64;
     // no operand-order copy of W1 (offsets past the bucket), no statistics for a next minibatch
     hipLaunchKernelGGL(k_adam_chain, dim3(nb_upd), dim3(kThreads), 0, s, params, grads, exp_avg, exp_avg_sq, n_params, sq_part,
-                       (n_params + 63) / 64, (float)max_norm, lr_dev, step_dev, beta1, beta2, eps, out_norm, 1.0f, nb_upd, n_params,
-                       n_params, 1, (float*)nullptr, n_params, n_params, (unsigned short*)nullptr, n_params, n_params, 1, 2,
-                       (const float4*)nullptr, 1, (const int32_t*)nullptr, 0,
+                       (n_params + 63) / 64, (float)max_norm, lr_dev, step_dev, beta1, beta2, eps, out_norm, 1.0f, nb_upd,
+                       no_operand_copies(n_params), (const float4*)nullptr, 1, (const int32_t*)nullptr, 0,
                        (double (*)[2]) nullptr);
     AURPPO_LAUNCH_CHECK("k_adam_chain");
     return AURPPO_OK;
@@ -699,11 +716,12 @@ extern "C" int aurppo_mlp_ppo_apply_f32(float* params, float* grads, float* exp_
     int nb_upd = (n_params + kThreads * 4 - 1) / (kThreads * 4);
     if (nb_upd > 64) nb_upd = 64;
     const int nsb = next_idx ? stat_blocks_for(next_M) : 0;
+    const OperandCopies oc_apply = {layout_h[0], layout_h[6], D, w1op, layout_h[2], layout_h[8],
+                                    aurppo_knobs().k7_variant >= 3 ? wv.wop3 : (unsigned short*)nullptr, layout_h[4], layout_h[10],
+                                    A_apply, aurppo_knobs().k7_variant};
     hipLaunchKernelGGL(k_adam_chain, dim3(nb_upd + nsb), dim3(kThreads), 0, (hipStream_t)stream, params, grads, exp_avg,
                        exp_avg_sq, n_params, (const double*)nullptr, 0, (float)max_norm, lr_dev, step_dev, beta1, beta2, eps,
-                       out_norm, (float)grad_scale, nb_upd, layout_h[0], layout_h[6], D, w1op, layout_h[2], layout_h[8],
-                       aurppo_knobs().k7_variant >= 3 ? wv.wop3 : (unsigned short*)nullptr, layout_h[4], layout_h[10], A_apply,
-                       aurppo_knobs().k7_variant,
+                       out_norm, (float)grad_scale, nb_upd, oc_apply,
                        reinterpret_cast<const float4*>(rec), rec_floats == 16 ? 4 : 1, next_idx, next_idx ? next_M : 0,
                        reinterpret_cast<double (*)[2]>(stats));
     AURPPO_LAUNCH_CHECK("k_adam_chain");

@@ -52,6 +52,9 @@ struct aurppo_rng {
     hipStream_t post_stream;   // AURPPO_K2_POST_STREAM=1: link + resolve run here, beside the next accept AND the next fill
     int use_post;
     hipEvent_t ev_fill[2], ev_acc[2], ev_link[2], ev_post[2], ev_res, ev_sync;
+    unsigned long long* d_relay;   // k_fy_accept3: one word per chunk of draws {launch tag, index after the chunk} + the `done` word
+    int relay_cap;
+    unsigned acc_gen;    // launch tag of the next k_fy_accept3 (never reset: a stale word of an earlier shuffle must not match)
     long seq;            // shuffles issued since the last (re)seed
     double primed_need;  // words-per-shuffle the look-ahead fill was sized for (0: nothing in flight)
 };
@@ -763,6 +766,445 @@ __global__ __launch_bounds__(kWaves * 64) void k_fy_accept2(const uint32_t* __re
 #endif
 }
 
+// k_fy_accept3 -- the relay of k_fy_accept2 between WORKGROUPS, with k_fy_accept's fixed point inside each.
+//
+// k_fy_accept is one workgroup walking the draw stream 8192 draws at a time: ~89 steps of ~4.6 us per 524 288-element shuffle,
+// every one on the chain (in-situ 437 us per shuffle, four per update: the longest pipeline of the update in round 3).  What a
+// stretch of draws needs from everything before it is ONE number, the index it starts at; where it starts in the stream is
+// known beforehand, because every chunk but the last consumes all of its draws.  So:
+//   * G workgroups (one per spare CU) own chunks g, g + G, ... of 1024 x kWpt consecutive draws (32 768 at kWpt = 32: 23 chunks
+//     per shuffle of 524 288);
+//   * a workgroup solves its chunk AHEAD of time from a guessed starting index (expected trajectory from the latest chunk anybody
+//     has confirmed), with k_fy_accept's rounds -- one workgroup barrier each --, and forms the window [LO, HI] of starting indices
+//     for which every lane's count stands;
+//   * thread 0 then polls its predecessor's word {launch tag, index after the chunk} (coherent loads); inside the window it
+//     publishes its own word at once -- the chain per chunk is then one cross-workgroup hop --, otherwise the workgroup re-runs
+//     the rounds from the true index (the lanes whose slack was exceeded recount) and publishes after;
+//   * targets are emitted after the word is out.  The workgroup that ends the shuffle (or runs out of draws) writes the cursor
+//     and raises the `done` word, on which everybody still waiting leaves.
+// Decisions and the words consumed are exactly numpy's: the same literal rule decides wherever a shortcut does not apply.
+template <int kAccThreads, int kWpt>
+__global__ __launch_bounds__(kAccThreads) void k_fy_accept3(const uint32_t* __restrict__ ring, long long ring_cap,
+                                                            int32_t* __restrict__ j, int n, long long* __restrict__ posv,
+                                                            int done_slot, unsigned long long* __restrict__ relay, int relay_cap,
+                                                            unsigned gen) {
+    constexpr int kChunk = kAccThreads * kWpt;
+    constexpr int kWaves = kAccThreads / kWave;
+    static_assert(kWaves >= 1 && kWaves <= 16, "wave sums are combined inside one DPP row");
+    static_assert(kWpt % 4 == 0 && kWpt <= kRingMirror, "draws are fetched four at a time from a mirrored ring");
+    __shared__ int s_wsum[2][kWaves];
+    __shared__ int s_chg[2][kWaves];
+    __shared__ int s_lo[kWaves], s_hi[kWaves];
+    __shared__ int s_ref[2];
+    __shared__ int s_start, s_fast;
+    constexpr int kListCap = 2048;
+    __shared__ unsigned long long s_list[kListCap];
+    // the chunk's targets, in index order, before they go to memory as whole lines (the dynamic allocation: kChunk words.  Stored
+    // straight from the lanes they were 4-byte stores ~90 B apart -- one line per lane and instruction, ~24 k of them per chunk,
+    // whose drain the next chunk's first wait then sat behind: 58 k cycles per chunk)
+    extern __shared__ int32_t s_stage[];
+    const int tid = threadIdx.x, lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int G = gridDim.x;
+    const long long cursor0 = posv[1];                // stream offset of the first unread draw
+    const long long avail = posv[0];                  // draws written so far (the fill for this shuffle has completed)
+    unsigned long long* const done_word = relay + relay_cap;
+    auto pack = [&](int i) -> unsigned long long { return ((unsigned long long)gen << 32) | (unsigned long long)(unsigned)i; };
+    auto tagged = [&](unsigned long long e) -> bool { return (unsigned)(e >> 32) == gen; };
+    auto cload = [](const unsigned long long* p) -> unsigned long long { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto cstore = [](unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    uint32_t ynext[kWpt];
+    long long r_next = (cursor0 + (long long)blockIdx.x * kChunk + (long long)tid * kWpt) % ring_cap;
+    const long long r_step = ((long long)G * kChunk) % ring_cap;
+    auto fetch = [&]() {             // branch-free: draws past `avail` come from some valid slot and are never looked at
+        const long long r0 = r_next;
+        r_next += r_step;
+        if (r_next >= ring_cap) r_next -= ring_cap;
+        const u32x4u* src = reinterpret_cast<const u32x4u*>(ring + r0);
+#pragma unroll
+        for (int q = 0; q < kWpt / 4; ++q) {
+            const u32x4u v = src[q];
+            ynext[4 * q + 0] = v.x; ynext[4 * q + 1] = v.y; ynext[4 * q + 2] = v.z; ynext[4 * q + 3] = v.w;
+        }
+    };
+    fetch();
+    int par = 0;                                      // exchange-buffer parity (runs on across chunks)
+#ifdef AURPPO_ACC_STAMPS   // tools/accept_stamps.py: thread 0 of workgroup 1 (a steady-state member of the relay), cycles per section
+    unsigned long long t_cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = __builtin_readcyclecounter();
+    unsigned long long t_chunks = 0, t_fast = 0, t_list = 0, t_ent = 0, t_delta = 0, t_rounds = 0, t_w = 0;
+#define TST(k) do { if (tid == 0) { const unsigned long long t__ = __builtin_readcyclecounter(); t_cyc[k] += t__ - t_last; t_last = t__; } } while (0)
+#else
+#define TST(k) do { } while (0)
+#endif
+    for (int c = blockIdx.x; c < relay_cap; c += G) {
+        const long long cbase = cursor0 + (long long)c * kChunk;
+        uint32_t y[kWpt];
+        int nhave = 0;                                // my draws that exist (a prefix of the kWpt)
+#pragma unroll
+        for (int u = 0; u < kWpt; ++u) {
+            y[u] = ynext[u];
+            nhave += (cbase + (long long)tid * kWpt + u) < avail ? 1 : 0;
+        }
+        fetch();
+        int stage_top = 0;                            // the chunk's first index (set before anything is emitted)
+        // the literal rule for my draws from starting index i0: #accepted; optionally stages targets / #consumed
+        auto walk = [&](int i0, bool emit, int& consumed) -> int {
+            int i = i0, acc = 0;
+            consumed = 0;
+#pragma unroll
+            for (int u = 0; u < kWpt; ++u) {
+                if (u < nhave && i >= 1) {
+                    const uint32_t v = y[u] & (0xffffffffu >> __clz(i));
+                    ++consumed;
+                    if (v <= (uint32_t)i) {
+                        if (emit) s_stage[stage_top - i] = (int32_t)v;
+                        --i;
+                        ++acc;
+                    }
+                }
+            }
+            return acc;
+        };
+        uint32_t dn = 0, up = 0;
+        bool sure = false;
+        int ref_i0 = 0;
+        bool wave_fast = false;
+        auto eval = [&](int i0) -> int {          // as in k_fy_accept: #draws <= i0 - kWpt, and the slack of that count
+            const bool shape = nhave == kWpt && i0 > kWpt && __clz(i0) == __clz(i0 - kWpt);
+            const uint32_t mask = 0xffffffffu >> __clz(i0 | 1);
+            const uint32_t lo = (uint32_t)(i0 - kWpt);
+            int cc = 0;
+            uint32_t d = 0xffffffffu, pp = 0xffffffffu;
+#pragma unroll
+            for (int u = 0; u < kWpt; ++u) {
+                const uint32_t v = y[u] & mask;
+                const bool le = v <= lo;
+                cc += le ? 1 : 0;
+                d = le ? min(d, lo - v) : d;
+                pp = le ? pp : min(pp, v - lo - 1u);
+            }
+            dn = d;
+            up = pp;
+            sure = shape && pp >= (uint32_t)kWpt;
+            ref_i0 = i0;
+            wave_fast = __builtin_amdgcn_ballot_w64(!sure) == 0ull;
+            if (!wave_fast) {
+                int consumed;
+                cc = walk(i0, false, consumed);
+            }
+            return cc;
+        };
+        auto still_ok = [&](int i0) -> bool {
+            const int delta = i0 - ref_i0;
+            const bool shape = i0 > kWpt && __clz(i0) == __clz(i0 - kWpt) && __clz(i0) == __clz(ref_i0);
+            const bool room = delta >= 0 ? up >= (uint32_t)(kWpt + delta) : dn >= (uint32_t)(-delta);
+            return delta == 0 || (sure && shape && room);
+        };
+        // ---- where to start from: the chunk before mine if it is confirmed already, else a guess from the latest confirmed one
+        int i_start = n - 1;
+        bool have_start = c == 0;
+        int c_ref_kept = c - 1;
+        if (c > 0) {
+            if (wave == 0) {
+                const int cc = c - 1 - lane;
+                const unsigned long long e = cc >= 0 ? cload(&relay[cc]) : 0ull;
+                const unsigned long long dw = cload(done_word);
+                const unsigned long long ok = __builtin_amdgcn_ballot_w64(cc >= 0 && tagged(e));
+                int c_ref = -1, i_ref = n - 1;
+                if (ok) {
+                    const int L = __builtin_ctzll(ok);
+                    c_ref = c - 1 - L;
+                    i_ref = __builtin_amdgcn_readlane((int)(unsigned)e, L);
+                }
+                if (tagged(dw)) { c_ref = c - 1; i_ref = 0; }   // the shuffle is over
+                if (lane == 0) { s_ref[0] = c_ref; s_ref[1] = i_ref; }
+            }
+            __syncthreads();
+            const int c_ref = s_ref[0], i_ref = s_ref[1];
+            __syncthreads();          // (s_ref is rewritten for the next chunk)
+            if (i_ref < 1) break;     // the shuffle ended before this chunk
+            c_ref_kept = c_ref;
+            if (c_ref == c - 1) {
+                i_start = i_ref;
+                have_start = true;
+            } else {
+                // expected trajectory: di/dp = -(i + 1) / (mask + 1), octave by octave (the mask halves where i crosses a power of two)
+                float fi = (float)(i_ref + 1), between = (float)(c - 1 - c_ref) * (float)kChunk;
+                float m1 = (float)(0xffffffffu >> __clz(i_ref | 1)) + 1.0f;
+                for (int k = 0; k < 32; ++k) {
+                    const float to_edge = m1 * __logf(fi / (0.5f * m1));      // draws until i + 1 reaches the bottom of this octave
+                    if (between <= to_edge || m1 <= 2.0f) {
+                        fi *= __expf(-between / m1);
+                        break;
+                    }
+                    between -= to_edge;
+                    fi = 0.5f * m1;
+                    m1 *= 0.5f;
+                }
+                i_start = (int)fi - 1;
+            }
+        }
+        TST(0);      // draws in registers, next fetch issued, reference for the guess read
+        // ---- k_fy_accept's fixed point over the chunk, from starting index i_cur (first call: from the expected trajectory)
+        int cur_i0, cnt, incl, total = 0, wbase = 0;
+        bool wchg = true;
+        auto rounds = [&](int i_cur) {
+            for (;;) {
+#ifdef AURPPO_ACC_STAMPS
+                ++t_rounds;
+#endif
+                if (lane == kWave - 1) {
+                    s_wsum[par][wave] = incl;
+                    s_chg[par][wave] = wchg ? 1 : 0;
+                }
+                __syncthreads();
+                const int ws = lane < kWaves ? s_wsum[par][lane] : 0;
+                const int wc = lane < kWaves ? s_chg[par][lane] : 0;
+                par ^= 1;
+                const int pre = row_incl_scan(ws);                          // lanes 0..15: prefix over the wave sums
+                total = __builtin_amdgcn_readlane(pre, kWaves - 1);
+                wbase = wave > 0 ? __builtin_amdgcn_readlane(pre, wave > 0 ? wave - 1 : 0) : 0;
+                const bool any = __builtin_amdgcn_ballot_w64(wc != 0) != 0ull;
+                if (!any) break;     // no wave's counts moved in the last evaluation: (cur_i0, cnt) is the fixed point
+                cur_i0 = i_cur - (wbase + incl - cnt);
+                if (__builtin_amdgcn_ballot_w64(!still_ok(cur_i0)) == 0ull) {
+                    wchg = false;
+                } else {
+                    const int cnt2 = eval(cur_i0);
+                    wchg = __builtin_amdgcn_ballot_w64(cnt2 != cnt) != 0ull;
+                    cnt = cnt2;
+                    incl = wave_incl_scan(cnt);
+                }
+            }
+        };
+        {
+            // expected index at my first draw (same trajectory, tid * kWpt draws on)
+            float fi = (float)(i_start + 1), between = (float)(tid * kWpt);
+            float m1 = (float)(0xffffffffu >> __clz(i_start | 1)) + 1.0f;
+            for (int k = 0; k < 32; ++k) {
+                const float to_edge = m1 * __logf(fi / (0.5f * m1));
+                if (between <= to_edge || m1 <= 2.0f) {
+                    fi *= __expf(-between / m1);
+                    break;
+                }
+                between -= to_edge;
+                fi = 0.5f * m1;
+                m1 *= 0.5f;
+            }
+            cur_i0 = i_start >= 1 ? (int)fi - 1 : i_start;
+            cnt = eval(cur_i0);
+            incl = wave_incl_scan(cnt);
+            rounds(i_start);
+        }
+        TST(1);      // solved from the guess (or from the confirmed start)
+        if (!have_start) {
+            // ---- what the true starting index can change: the SENSITIVE draws.  Along the guessed solution draw p is tried against
+            // index idx(p); with the chunk starting `c` higher or lower, |c| <= W, it is tried against idx(p) + c.  A draw whose
+            // decision is the same over that whole range (same mask octave, value outside [idx - W, idx + W]) cannot change; the
+            // others go, in stream order, into a list {raw word, idx(p), decision} in LDS.  Given the true start, the index after
+            // the chunk then follows from a walk over the list alone (the literal rule per entry, the offset c carried along) --
+            // one wave, no barrier -- which is all the chain has to wait for; the lanes' own counts are redone after the word is out.
+            const int sigma_draws = (c - 1 - c_ref_kept) * kChunk + kChunk;
+            const int W = min(max((int)(2.0f * __fsqrt_rn((float)sigma_draws)), 64), 4096);   // 4 sigma of the guess (sigma^2 <= draws / 4); beyond it: the slow path
+            unsigned long long ent[kWpt / 4];      // (a lane keeps at most kWpt / 4 entries in registers; more: overflow)
+            int n_ent = 0;
+            {
+                int i = cur_i0;
+#pragma unroll
+                for (int u = 0; u < kWpt; ++u) {
+                    const bool live = u < nhave;
+                    const bool pos = i >= 1;
+                    const uint32_t mask = 0xffffffffu >> __clz(i | 1);
+                    const uint32_t v = y[u] & mask;
+                    const bool acc = live && pos && v <= (uint32_t)i;
+                    const bool same_oct = i - W >= 1 && __clz(i - W) == __clz(i + W);
+                    const bool fixed = same_oct && (v + (uint32_t)W <= (uint32_t)i || v > (uint32_t)(i + W));
+                    if (live && !fixed) {
+                        const unsigned long long e = ((unsigned long long)y[u] << 32) | ((unsigned long long)(unsigned)(i & 0x7fffffff) << 1) | (acc ? 1ull : 0ull);
+                        // i may be <= 0 past the end of the shuffle: kept as a 31-bit two's complement
+#pragma unroll
+                        for (int q = 0; q < kWpt / 4; ++q)
+                            if (q == n_ent) ent[q] = e;
+                        ++n_ent;
+                    }
+                    i -= acc ? 1 : 0;
+                }
+            }
+            const int e_incl = wave_incl_scan(n_ent);
+            if (lane == kWave - 1) s_lo[wave] = e_incl;
+            const bool lane_over = n_ent > kWpt / 4;
+            if (__builtin_amdgcn_ballot_w64(lane_over) != 0ull && lane == 0) s_hi[wave] = 1; else if (lane == 0) s_hi[wave] = 0;
+            __syncthreads();
+            int e_base = 0, e_total = 0, over = 0;
+            for (int w = 0; w < kWaves; ++w) {
+                const int t = s_lo[w];
+                e_base += w < wave ? t : 0;
+                e_total += t;
+                over |= s_hi[w];
+            }
+            const bool use_list = !over && e_total <= kListCap;
+            if (use_list) {
+                const int at = e_base + e_incl - n_ent;
+#pragma unroll
+                for (int q = 0; q < kWpt / 4; ++q)
+                    if (q < n_ent) s_list[at + q] = ent[q];
+            }
+            __syncthreads();
+            TST(2);      // sensitive draws listed
+#ifdef AURPPO_ACC_STAMPS
+            t_list += use_list ? 1 : 0;
+            t_ent += (unsigned long long)e_total;
+            t_w += (unsigned long long)W;
+#endif
+            if (wave == 0) {
+                // ---- the relay: my predecessor's word.  From here to the store of my own is the critical path of the whole shuffle
+                __builtin_amdgcn_s_setprio(3);
+                int i_exact = 0;
+                if (lane == 0) {
+                    for (;;) {
+                        const unsigned long long e = cload(&relay[c - 1]);
+                        const unsigned long long dw = cload(done_word);
+                        if (tagged(e)) { i_exact = (int)(unsigned)e; break; }
+                        if (tagged(dw)) { i_exact = 0; break; }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                i_exact = __builtin_amdgcn_readfirstlane(i_exact);
+                TST(3);      // waited for the predecessor
+#ifdef AURPPO_ACC_STAMPS
+                t_delta += (unsigned long long)abs(i_exact - i_start);
+#endif
+                int fast = 0;
+                if (i_exact >= 1 && use_list) {
+                    // walk the list, 64 entries at a time: within a block the offsets are the fixed point of
+                    // "c_l = c_in + (decisions flipped by earlier lanes)", iterated to rest (a flip is rare)
+                    int cin = i_exact - i_start;
+                    bool in_range = abs(cin) <= W;
+                    for (int b0 = 0; b0 < e_total && in_range; b0 += kWave) {
+                        const bool have = b0 + lane < e_total;
+                        const unsigned long long e = have ? s_list[b0 + lane] : 0ull;
+                        const uint32_t yy = (uint32_t)(e >> 32);
+                        const int i_sp = ((int)(((unsigned)e >> 1) << 1)) >> 1;      // sign-extend the 31-bit index
+                        const int a_sp = (int)(e & 1ull);
+                        int cl = cin, flip = 0;
+                        for (;;) {
+                            const int i_now = i_sp + cl;
+                            const uint32_t v = yy & (0xffffffffu >> __clz(i_now | 1));
+                            const int a_now = (have && i_now >= 1 && v <= (uint32_t)i_now) ? 1 : 0;
+                            const int f2 = have ? a_sp - a_now : 0;             // the index after this draw moves by this much
+                            const bool moved = f2 != flip;
+                            flip = f2;
+                            const int incl = wave_incl_scan(flip);
+                            cl = cin + incl - flip;
+                            if (__builtin_amdgcn_ballot_w64(moved) == 0ull) {
+                                const int lo_c = min(cl, cl + flip), hi_c = max(cl, cl + flip);
+                                in_range = __builtin_amdgcn_ballot_w64(have && (lo_c < -W || hi_c > W)) == 0ull;
+                                cin += __builtin_amdgcn_readlane(incl, kWave - 1);
+                                break;
+                            }
+                        }
+                    }
+                    if (in_range) {
+                        const int i_end = (i_start - total) + cin;
+                        const bool last = i_end <= 0;                            // every remaining index gets its target in this chunk
+                        const bool dry = !last && cbase + kChunk >= avail;       // ... or the draws run out first
+                        if (lane == 0) {
+                            cstore(&relay[c], pack((last || dry) ? 0 : i_end));
+                            if (last || dry) cstore(done_word, pack(1));
+                        }
+                        fast = 1;
+                    }
+                }
+                __builtin_amdgcn_s_setprio(0);
+                TST(4);      // list walked, word published (fast path)
+#ifdef AURPPO_ACC_STAMPS
+                t_fast += fast ? 1 : 0;
+#endif
+                if (lane == 0) {
+                    s_start = i_exact;
+                    s_fast = fast;
+                }
+            }
+            __syncthreads();
+            const int i_exact = s_start;
+            const bool fast = s_fast != 0;
+            if (i_exact < 1) break;                   // the shuffle ended before this chunk
+            if (i_exact != i_start) {
+                cur_i0 = i_exact - (wbase + incl - cnt);
+                if (__builtin_amdgcn_ballot_w64(!still_ok(cur_i0)) == 0ull) {
+                    wchg = false;
+                } else {
+                    const int cnt2 = eval(cur_i0);
+                    wchg = __builtin_amdgcn_ballot_w64(cnt2 != cnt) != 0ull;
+                    cnt = cnt2;
+                    incl = wave_incl_scan(cnt);
+                }
+                rounds(i_exact);
+            }
+            i_start = i_exact;
+            have_start = !fast;      // (fast: the word is out already)
+        }
+        TST(5);      // counts redone from the true start
+#ifdef AURPPO_ACC_STAMPS
+        ++t_chunks;
+#endif
+        const bool last = total >= i_start;
+        const bool dry = !last && cbase + kChunk >= avail;
+        if (have_start && tid == 0) {
+            cstore(&relay[c], pack((last || dry) ? 0 : i_start - total));
+            if (last || dry) cstore(done_word, pack(1));
+        }
+        // ---- off the chain: the targets, staged in index order, then stored as whole lines
+        int consumed = kWpt;
+        stage_top = i_start;
+        if (!wave_fast || last) {
+            (void)walk(cur_i0, true, consumed);
+        } else {
+            const uint32_t mask = 0xffffffffu >> __clz(cur_i0 | 1);
+            const uint32_t lo = (uint32_t)(cur_i0 - kWpt);
+            int i = cur_i0;
+#pragma unroll
+            for (int u = 0; u < kWpt; ++u) {
+                const uint32_t v = y[u] & mask;
+                if (v <= lo) s_stage[stage_top - (i--)] = (int32_t)v;
+            }
+        }
+        __syncthreads();
+        {
+            const int n_out = last ? i_start : total;         // indices i_start .. i_start - n_out + 1
+            for (int q = tid; q < n_out; q += kAccThreads) j[i_start - q] = s_stage[q];
+        }
+        TST(6);      // targets emitted
+        if (last) {
+            // words consumed = everything up to and including the draw that filled i = 1 (unique thread)
+            if (cnt > 0 && cur_i0 - cnt == 0) {
+                const long long end = cbase + (long long)tid * kWpt + consumed;
+                posv[1] = end;
+                posv[done_slot] = end;
+            }
+            break;
+        }
+        if (dry) {
+            if (tid == 0) {
+                const long long end = cbase + (avail - cbase < kChunk ? avail - cbase : kChunk);
+                posv[1] = end;
+                posv[done_slot] = end;
+                posv[2] = 1;      // ran out of draws before the shuffle finished: sticky error
+            }
+            break;
+        }
+    }
+#ifdef AURPPO_ACC_STAMPS
+    if (tid == 0 && blockIdx.x == (G > 1 ? 1 : 0)) {
+        for (int q = 0; q < 7; ++q) posv[8 + q] = (long long)t_cyc[q];
+        posv[15] = (long long)t_chunks; posv[16] = (long long)t_fast; posv[17] = (long long)t_list; posv[18] = (long long)t_ent;
+        posv[19] = (long long)t_delta; posv[20] = (long long)t_rounds; posv[21] = (long long)t_w;
+    }
+#endif
+#undef TST
+}
+
 // Side job: clr[0 .. clr_n) = -1 (clr_n a multiple of 4, 16-B aligned) -- the list heads the NEXT shuffle links into.
 // (It was a memset between accept and link: 5 us of work that had to find a free CU beside K7, ~100 us in-situ; as
 // stores inside the single-workgroup accept kernel it cost that kernel 20-40 us.)
@@ -880,6 +1322,10 @@ constexpr int kAccWpt = AURPPO_ACC_WPT;
 #define AURPPO_ACC2_WPT 16    // draws per lane and chunk
 #endif
 constexpr int kAcc2Waves = AURPPO_ACC2_WAVES, kAcc2Wpt = AURPPO_ACC2_WPT;
+#ifndef AURPPO_ACC3_WPT
+#define AURPPO_ACC3_WPT 16    // draws per thread and chunk of the workgroup relay (k_fy_accept3): 16 384 per chunk (32: the kernel spills)
+#endif
+constexpr int kAcc3Wpt = AURPPO_ACC3_WPT, kAcc3Chunk = 1024 * kAcc3Wpt;
 constexpr size_t kOwnCuLds = 81 * 1024;
 static hipError_t own_cu_setup() {
     static bool done_of[kMaxDevices] = {false};
@@ -893,6 +1339,9 @@ static hipError_t own_cu_setup() {
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fy_accept2<kAcc2Waves, kAcc2Wpt>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kOwnCuLds);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fy_accept3<1024, kAcc3Wpt>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(int32_t) * kAcc3Chunk));
     done = e == hipSuccess;
     return e;
 }
@@ -947,7 +1396,18 @@ int permute_once(aurppo_rng* rng, const int32_t* in, int32_t* out, int n, hipStr
         AURPPO_HIP_TRY(hipMemsetAsync(rng->d_head[h], 0xff, sizeof(int32_t) * (size_t)n, ls));
         rng->head_clean[h] = n;
     }
-    if (aurppo_knobs().k2_accept == 1)
+    if (aurppo_knobs().k2_accept == 3) {
+        // G workgroups, one per CU (each asks for more than half a CU's LDS): as many as K7 leaves free beside the twist, and no
+        // more than the shuffle has chunks
+        int G = aurppo_knobs().k2_accept3_wgs;
+        const int chunks = (int)(need / kAcc3Chunk) + 1;
+        if (G > chunks) G = chunks;
+        if (G < 1) G = 1;
+        rng->acc_gen += 1;
+        if (rng->acc_gen == 0) rng->acc_gen = 1;     // (0 is what the buffer is cleared to)
+        hipLaunchKernelGGL((k_fy_accept3<1024, kAcc3Wpt>), dim3(G), dim3(1024), sizeof(int32_t) * kAcc3Chunk, s, rng->d_ring, (long long)rng->ring_cap,
+                           rng->d_j[slot], n, rng->d_pos, 4 + slot, rng->d_relay, rng->relay_cap, rng->acc_gen);
+    } else if (aurppo_knobs().k2_accept == 1)
         hipLaunchKernelGGL((k_fy_accept<1024, kAccWpt>), dim3(1), dim3(1024), kOwnCuLds, s, rng->d_ring, (long long)rng->ring_cap,
                            rng->d_j[slot], n, rng->d_pos, 4 + slot);
     else
@@ -1037,6 +1497,9 @@ extern "C" int aurppo_mt19937_create(aurppo_rng** out, uint32_t seed, int max_n,
     if (e == hipSuccess) e = hipMalloc(&r->d_last, sizeof(uint32_t) * kMtN);
     if (e == hipSuccess) e = hipMalloc(&r->d_ring, sizeof(uint32_t) * (r->ring_cap + kRingMirror));
     if (e == hipSuccess) e = hipMalloc(&r->d_pos, sizeof(long long) * 32);
+    r->relay_cap = (int)(r->ring_cap / kAcc3Chunk) + 4;
+    if (e == hipSuccess) e = hipMalloc(&r->d_relay, sizeof(unsigned long long) * (size_t)(r->relay_cap + 1));
+    if (e == hipSuccess) e = hipMemset(r->d_relay, 0, sizeof(unsigned long long) * (size_t)(r->relay_cap + 1));
     for (int k = 0; k < 2 && e == hipSuccess; ++k) {
         e = hipMalloc(&r->d_j[k], nb);
         if (e == hipSuccess) e = hipMalloc(&r->d_next[k], nb);
@@ -1078,6 +1541,7 @@ extern "C" int aurppo_mt19937_destroy(aurppo_rng* rng) {
     (void)hipFree(rng->d_last);
     (void)hipFree(rng->d_ring);
     (void)hipFree(rng->d_pos);
+    (void)hipFree(rng->d_relay);
     for (int k = 0; k < 2; ++k) {
         (void)hipFree(rng->d_j[k]);
         (void)hipFree(rng->d_next[k]);
