@@ -11,14 +11,14 @@
 //      x[m] = x[m-227] ^ mix(x[m-624], x[m-623]): a lane owns one offset of every phase (x[m-227] is its own previous
 //      output, a register), two phases share a barrier, and four helper waves temper and store the words to a ring in
 //      HBM one barrier behind the four that twist.  It runs one shuffle ahead of its consumer on the handle's own stream.
-//   1b. k_fy_accept -- one 1024-thread workgroup turns 8192 draws per step into accept/reject
-//      decisions.  Whether draw p is accepted depends on the index i it is tried against, i.e. on how
-//      many earlier draws were accepted -- a triangular system.  Each thread resolves its own 8
-//      consecutive draws exactly given its starting index; the starting indices are the fixed point of
-//      "i_t = i0 - (#accepts of earlier threads)", iterated with ballot-free prefix sums until no
-//      count changes (2-3 rounds: a draw is ambiguous only if its value lands within the error of the
-//      guess, and the first guess uses the acceptance rate of the previous step).  ~90 sequential
-//      steps per 524288-element shuffle instead of ~1170.  Output: the swap targets j[1..n).
+//   1b. k_fy_accept3 (default; k_fy_accept / k_fy_accept2 are the one-workgroup builds it grew from) -- turns the draws into
+//      accept/reject decisions.  Whether draw p is accepted depends on the index i it is tried against, i.e. on how
+//      many earlier draws were accepted -- a triangular system.  A thread resolves its own consecutive draws exactly
+//      given its starting index; inside a workgroup the starting indices are the fixed point of
+//      "i_t = i0 - (#accepts of earlier threads)", iterated with prefix sums until no count changes; BETWEEN workgroups
+//      only the index at a chunk boundary is handed on, and a workgroup has solved its 16 384-draw chunk from a guessed
+//      index -- and listed the few hundred draws the true one can change -- before its predecessor's word arrives.
+//      Output: the swap targets j[1..n).
 //   2. k_fy_link / k_fy_resolve -- given j, the final content of every position is found in
 //      parallel with no swaps at all (link behind the accept; resolve on the fill stream, beside the NEXT accept).  Step s writes old x[s] into position j_s, so "what sits in
 //      position q just before step t" is "what step min{s>t : j_s=q} put there", recursively.
@@ -125,7 +125,9 @@ constexpr int kPair = 2 * kMtD;  // words per barrier interval
 // slots the producers leave free while they wait for LDS.  (First version: every lane tempered and stored its own
 // words between the LDS writes and the barrier -- ~95 instructions per wave on the chain, 750 cycles per interval.
 // With four helper waves taking two words each, one after the other, the helpers were the last to reach the barrier:
-// eight of them take one word each.)
+// eight of them take one word each.  Round 3 tried the ring UNTEMPERED -- four waves only, each lane storing its own two words
+// behind the barrier, the consumers tempering what they read: 429 us per shuffle's draws against 360, the stores' address
+// arithmetic and exec branches being back on the chain.)
 __global__ __launch_bounds__(kFillAll) void k_mt_fill(uint32_t* __restrict__ last, uint32_t* __restrict__ ring,
                                                       long long ring_cap, long long* __restrict__ posv,
                                                       long long target, int nblk_max, int cur_slot) {

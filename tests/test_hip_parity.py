@@ -158,6 +158,30 @@ def test_shuffle_inplace_matches_numpy_any_seed(H, seed, n):
     assert pos == st[2]
 
 
+@pytest.mark.parametrize("accept,wgs", [("1", "6"), ("2", "6"), ("3", "1"), ("3", "2"), ("3", "6"), ("3", "8")])
+def test_shuffle_every_accept_kernel_matches_numpy(H, accept, wgs, monkeypatch):
+    """The three builds of the accept stage (k_fy_accept: one workgroup, rounds; k_fy_accept2: wave relay; k_fy_accept3: workgroup
+    relay, the default) and the relay's widths, over sizes from below one 16 384-draw chunk to dozens of them, the stream carried
+    across consecutive shuffles: permutations and the generator state afterwards equal numpy's."""
+    monkeypatch.setenv("AURPPO_K2_ACCEPT", accept)
+    monkeypatch.setenv("AURPPO_K2_ACCEPT3_WGS", wgs)
+    for n in (2, 11, 1000, 11500, 12000, 23500, 40000, 70000, 300000, 524288):
+        rs = np.random.RandomState(7)
+        rng = H.MT19937(7, n)
+        got = rng.shuffle_epochs(n, 3).cpu().numpy()
+        idx = np.arange(n)
+        for e in range(3):
+            rs.shuffle(idx)
+            np.testing.assert_array_equal(got[e], idx, err_msg=f"accept {accept}, {wgs} workgroups, n={n}, shuffle {e}")
+        key, pos = rng.get_state()
+        st = rs.get_state()
+        np.testing.assert_array_equal(key, st[1])
+        assert pos == st[2]
+        status = torch.zeros(1, device="cuda")
+        rng.status_into(status)
+        assert float(status) == 0.0
+
+
 def test_shuffle_state_roundtrip_and_reseed(H):
     rng = H.MT19937(5, 1000)
     a = rng.shuffle_epochs(1000, 1).clone()
