@@ -191,10 +191,85 @@ __global__ __launch_bounds__(kThreads3, 1) void k_mlp_step3(const MlpArgs a) {
     int t1 = 0, t2 = 0, t3_raw = 0;
     const int n_sets = 2 * gridDim.x, my_set = 2 * blockIdx.x + set;
     const bool stat = a.static_tiles != 0;      // diagnostic: static stride, fixed summation order (see mlp2.hip)
+    // A minibatch of fewer than four tiles per set (BASELINE config 4's shard: one): the first three tiles of a set are its own by
+    // number, so every set starts without waiting for the counter -- the indices of all three, the first one's rows and the
+    // statistics are requested before anything else in the launch (prologue 9.1 -> 4.4 us at M = 16 384, tools/mlp_stamps.py).
+    // Larger ones: a workgroup draws its first eight tiles when it STARTS (beside the shuffle kernels some start late, and a
+    // tile fixed to a late workgroup waits for it: 2.15 -> 2.24 ms per update at M = 131 072 with the fixed start), the rest one
+    // by one from the counter.
     const bool fixed_start = !stat && n_tiles < 4 * n_sets;
-    const int dyn_base = fixed_start ? 2 * n_sets : 0;
-    int grab_raw = 0;
+    const bool early = fixed_start || stat;
+    const int dyn_base = fixed_start ? 3 * n_sets : 0;
 
+    const bool vec4 = (D % 4 == 0) && ((reinterpret_cast<size_t>(a.obs) & 15) == 0);
+    const float* const act_base = a.actions ? a.actions : reinterpret_cast<const float*>(a.rec) + 4;
+    const int act_stride = a.actions ? AW : 16;
+    float xr[8];
+    float ar[2], act_cur[2] = {0.0f, 0.0f};
+    float4 p_rec = make_float4(0.f, 0.f, 0.f, 0.f);
+    int p_src = -1;
+    bool x_ok[2] = {false, false}, a_ok[2] = {false, false};
+    // rows of a tile, given the sample indices of the rows this thread touches (s0 / s1: its two float4 rows, sl: its row of the
+    // 8-lanes-per-row layout, sp: wave 0's record row)
+    auto prefetch_src = [&](int s0, int s1, int sl_row, int sp, int st) {
+        const int lj = st & 7;
+        if (vec4) {
+            const int c4 = (st & 15) * 4;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int src = p == 0 ? s0 : s1;
+                x_ok[p] = src >= 0 && c4 < D;
+                const float4 v = *reinterpret_cast<const float4*>(a.obs + (x_ok[p] ? (size_t)src * D + c4 : (size_t)0));
+                xr[4 * p + 0] = v.x; xr[4 * p + 1] = v.y; xr[4 * p + 2] = v.z; xr[4 * p + 3] = v.w;
+            }
+        } else {
+            const int src = sl_row;
+            x_ok[0] = src >= 0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xr[u] = a.obs[(src >= 0 && lj + 8 * u < D) ? (size_t)src * D + lj + 8 * u : (size_t)0];
+        }
+        {
+            const int src = sl_row;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                a_ok[u] = src >= 0 && lj + 8 * u < AW;
+                ar[u] = act_base[a_ok[u] ? (size_t)src * act_stride + lj + 8 * u : (size_t)0];
+            }
+        }
+        if (w == 0) {
+            p_src = sp;
+            p_rec = a.rec[(size_t)(p_src >= 0 ? p_src : 0) * a.rec_stride];
+        }
+    };
+    auto prefetch = [&](const int* sidx, int st) {
+        prefetch_src(sidx[st >> 4], sidx[(st >> 4) + 16], sidx[st >> 3], w == 0 ? sidx[st & (R - 1)] : -1, st);
+    };
+    // ---- first of all: the sample indices of this set's first tile (tile number = set number), straight from the index list;
+    // its rows are requested as soon as they are here, beside the staging loads below.  (They used to wait for the tile grab,
+    // the staging and two workgroup barriers: 9.1 us of prologue before a 12 us tile at M = 16 384, tools/mlp_stamps.py.)
+    int e0 = -1, e1 = -1, el = -1, ep = -1, i1_early = -1;
+    if (early) {
+        auto gidx = [&](int row) -> int {
+            const int m = my_set * R + row;
+            const bool ok = my_set < n_tiles && m < a.h.M;
+            const int v = a.idx[ok ? m : 0];
+            return ok ? v : -1;
+        };
+        e0 = gidx(st >> 4);
+        e1 = gidx((st >> 4) + 16);
+        el = gidx(st >> 3);
+        ep = gidx(st & (R - 1));
+        if (w == 0) {
+            i1_early = load_idx(my_set + n_sets, st);
+            n_idx = load_idx(my_set + 2 * n_sets, st);
+        }
+    }
+    // (the advantage partial sums too: nothing below depends on anything but the launch arguments)
+    double st_s = 0.0, st_q = 0.0;
+    for (int b = tid; b < a.n_stat_blocks; b += kThreads3) {
+        st_s += a.stats[2 * b];
+        st_q += a.stats[2 * b + 1];
+    }
     // ---- this wave's weight slices, streamed in operand order: 12 fragments of 16 B per lane and matrix
     // (a wave-uniform base in scalar registers + the lane's 32-bit byte offset + an immediate per fragment: written as 36
     // 64-bit vector addresses they were formed once, hoisted out of the tile loop, spilled, and every load then waited behind
@@ -231,8 +306,11 @@ __global__ __launch_bounds__(kThreads3, 1) void k_mlp_step3(const MlpArgs a) {
             b3r = a.params[e < od ? b3 + e : b3];
         }
         if (tid < AP) lsr = a.params[(a.continuous && tid < A) ? a.L.logstd + tid : a.L.w2[0]];
-        if (tid == 0 && !stat) grab_raw = (int)atomicAdd(tile_counter + zero_off, fixed_start ? 2u : 8u);
+        int grab_raw = 0;
+        if (!early && tid == 0) grab_raw = (int)atomicAdd(tile_counter + zero_off, 8u);
         load_w(0);                                   // W1 slice of the first tile
+        if (early) prefetch_src(e0, e1, el, ep, st); // (the index loads are the oldest in flight: only they are waited for here)
+        if (tid == 0) s_grab = grab_raw;
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -261,19 +339,17 @@ __global__ __launch_bounds__(kThreads3, 1) void k_mlp_step3(const MlpArgs a) {
         for (int e = st; e < 2 * kDoNet / 16; e += kSetThreads) zd[e] = zero;
     }
     for (int e = tid; e < 2 * 6 * R; e += kThreads3) (&s_loss[0][0][0])[e] = 0.0;
-    if (tid == 0) s_grab = grab_raw;
     __syncthreads();
     if (w == 0) {
-        const int g = s_grab;
-        const int base_t = (fixed_start || stat) ? my_set : g + 4 * set;
-        t1 = (fixed_start || stat) ? my_set + n_sets : base_t + 1;
-        t2 = stat ? my_set + 2 * n_sets : (fixed_start ? dyn_base + g + set : base_t + 2);
+        const int base_t = early ? my_set : s_grab + 4 * set;
+        t1 = early ? my_set + n_sets : base_t + 1;
+        t2 = early ? my_set + 2 * n_sets : base_t + 2;
         if (stat) {
             t3_raw = my_set + 3 * n_sets;
-        } else if (fixed_start) {
-            if (lane == 0) t3_raw = (int)atomicAdd(tile_counter + zero_off, 1u);
-        } else {
+        } else if (!early) {
             t3_raw = base_t + 3;
+        } else if (lane == 0) {
+            t3_raw = (int)atomicAdd(tile_counter + zero_off, 1u);      // first used in the first tile's loss phase
         }
         if (lane == 0) {
             s_first[set] = base_t < n_tiles ? 1 : 0;
@@ -281,8 +357,8 @@ __global__ __launch_bounds__(kThreads3, 1) void k_mlp_step3(const MlpArgs a) {
             s_pbar[set][0] = 0;
             s_pbar[set][1] = 0;
         }
-        const int i0 = load_idx(base_t, st), i1 = load_idx(t1, st);
-        n_idx = load_idx(t2, st);
+        const int i0 = early ? ep : load_idx(base_t, st), i1 = early ? i1_early : load_idx(t1, st);
+        if (!early) n_idx = load_idx(t2, st);
         n_ok = n_idx >= 0;
         if (st < R) {
             sIdx[st] = i0;
@@ -291,13 +367,8 @@ __global__ __launch_bounds__(kThreads3, 1) void k_mlp_step3(const MlpArgs a) {
     }
     // ---- minibatch advantage statistics from the partials (same order in every workgroup)
     {
-        double s = 0.0, q = 0.0;
-        for (int b = tid; b < a.n_stat_blocks; b += kThreads3) {
-            s += a.stats[2 * b];
-            q += a.stats[2 * b + 1];
-        }
-        const double ts = block_sum<kThreads3 / kWave>(s, s_red[0]);
-        const double tq = block_sum<kThreads3 / kWave>(q, s_red[1]);
+        const double ts = block_sum<kThreads3 / kWave>(st_s, s_red[0]);
+        const double tq = block_sum<kThreads3 / kWave>(st_q, s_red[1]);
         if (tid == 0) {
             const double m = ts / (double)a.h.M;
             double var = (tq - ts * m) / (double)(a.h.M - 1);
@@ -311,6 +382,7 @@ __global__ __launch_bounds__(kThreads3, 1) void k_mlp_step3(const MlpArgs a) {
     const float mean = uniform(s_mean), denom = uniform(s_std + 1e-8f);
     const float invM = uniform(1.0f / (float)a.h.M);
     const float g_ent = uniform(-a.h.ent_coef * invM);
+    if (!early) prefetch(sIdx, st);
     float ent_sum = 0.0f;
     if (a.continuous)
         for (int k = 0; k < A; ++k) ent_sum += (0.5f + 0.9189385332046727f) + sLs[k];
@@ -323,46 +395,7 @@ __global__ __launch_bounds__(kThreads3, 1) void k_mlp_step3(const MlpArgs a) {
     float gb1 = 0.0f, gb2 = 0.0f;
     float g_b3a[2] = {0.0f, 0.0f}, g_ls[2] = {0.0f, 0.0f}, g_b3c = 0.0f;
 
-    const bool vec4 = (D % 4 == 0) && ((reinterpret_cast<size_t>(a.obs) & 15) == 0);
-    const float* const act_base = a.actions ? a.actions : reinterpret_cast<const float*>(a.rec) + 4;
-    const int act_stride = a.actions ? AW : 16;
-    float xr[8];
-    float ar[2], act_cur[2] = {0.0f, 0.0f};
-    float4 p_rec = make_float4(0.f, 0.f, 0.f, 0.f);
-    int p_src = -1;
-    bool x_ok[2] = {false, false}, a_ok[2] = {false, false};
-    auto prefetch = [&](const int* sidx, int st) {
-        const int lr = st >> 3, lj = st & 7;
-        if (vec4) {
-            const int c4 = (st & 15) * 4;
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const int src = sidx[(st >> 4) + 16 * p];
-                x_ok[p] = src >= 0 && c4 < D;
-                const float4 v = *reinterpret_cast<const float4*>(a.obs + (x_ok[p] ? (size_t)src * D + c4 : (size_t)0));
-                xr[4 * p + 0] = v.x; xr[4 * p + 1] = v.y; xr[4 * p + 2] = v.z; xr[4 * p + 3] = v.w;
-            }
-        } else {
-            const int src = sidx[lr];
-            x_ok[0] = src >= 0;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) xr[u] = a.obs[(src >= 0 && lj + 8 * u < D) ? (size_t)src * D + lj + 8 * u : (size_t)0];
-        }
-        {
-            const int src = sidx[lr];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                a_ok[u] = src >= 0 && lj + 8 * u < AW;
-                ar[u] = act_base[a_ok[u] ? (size_t)src * act_stride + lj + 8 * u : (size_t)0];
-            }
-        }
-        if (w == 0) {
-            p_src = sidx[st & (R - 1)];
-            p_rec = a.rec[(size_t)(p_src >= 0 ? p_src : 0) * a.rec_stride];
-        }
-    };
     __syncthreads();
-    prefetch(sIdx, st);
 
     int bar_gen = 0;
     auto set_bar = [&]() {
