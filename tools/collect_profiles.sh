@@ -1,7 +1,10 @@
 #!/bin/bash
 # Regenerates the round's committed evidence on the GPU box (outputs under gpurun_out/prof_final/; copy into profiles/rNN/):
 #   bench.json                          python bench.py (default flags: parity gate + cpu_baseline + both rooflines)
-#   bench_under_rocprof.json + bench_kernel_stats.csv            the same command under rocprofv3 --kernel-trace --stats
+#   bench_under_rocprof.json + bench_kernel_stats.csv            the same workload under rocprofv3 --kernel-trace --stats, with
+#                                       --shard-envs-per-gpu 0: the 512-env shard bench.py measures second in the same process launches the
+#                                       same kernels at M = 16 384 and would be averaged into the same rows
+#   bench_shard_*                       that shard alone (--envs-per-gpu 512), same way; bench_default_*: the default flags (both workloads, mixed rows)
 #   bench_nofused_*.json/csv            bench.py --no-fused-mlp (per-op path: K1, K3, K4+K5, K6b stand-alone durations)
 #   bench_forcedp_*.json/csv            bench.py --force-dp (the W > 1 launch path captured around a one-rank RCCL all-reduce)
 #   mlp3_pmc.json                       separate --pmc passes for the default K7 kernel's (k_mlp_step3) HBM traffic; mlp_pmc.json: k_mlp_step2's
@@ -29,7 +32,9 @@ prof() {  # prof <tag> <bench args...>
   cp $(ls $O/stats_$tag/*/*kernel_stats.csv | head -1) $O/${tag}_kernel_stats.csv
   rm -rf $O/stats_$tag
 }
-prof bench
+prof bench --shard-envs-per-gpu 0
+prof bench_shard --envs-per-gpu 512 --shard-envs-per-gpu 0
+prof bench_default
 prof bench_nofused --no-fused-mlp
 prof bench_forcedp --force-dp
 prof bench_wide_3x128 --hidden-dim 128 --num-layers 3 --steps 30
@@ -42,8 +47,9 @@ done
 run 600 python3 $R/tools/bench_wide.py > $O/wide_bench.json 2> $O/wide_bench.err
 for v in 2 3 4; do AURPPO_K7_VARIANT=$v run 300 python3 $R/tools/mlp_stamps.py > $O/k7_stamps_v$v.txt 2>&1; done
 (for m in 131072 16384; do for v in 3 2 4; do K7_M=$m AURPPO_K7_VARIANT=$v python3 $R/tools/k7_time.py 2>&1 | tail -1; done; done) > $O/k7_time.txt
-(for a in 1 2; do AURPPO_K2_ACCEPT=$a python3 $R/tools/k2_time.py 2>&1 | tail -1; done) > $O/k2_time.txt
-(AURPPO_K2_ACCEPT=1 python3 $R/tools/accept_stamps.py 2>&1 | tail -10; AURPPO_K2_ACCEPT=2 python3 $R/tools/accept_stamps.py 2>&1 | tail -8) > $O/k2_stamps.txt
+(for a in 3 1 2; do AURPPO_K2_ACCEPT=$a python3 $R/tools/k2_time.py 2>&1 | tail -1; done) > $O/k2_time.txt
+(AURPPO_K2_ACCEPT=3 python3 $R/tools/accept_stamps.py 2>&1 | tail -9; AURPPO_K2_ACCEPT=1 python3 $R/tools/accept_stamps.py 2>&1 | tail -10; AURPPO_K2_ACCEPT=2 python3 $R/tools/accept_stamps.py 2>&1 | tail -8) > $O/k2_stamps.txt
+(K7_M=16384 AURPPO_K7_VARIANT=3 python3 $R/tools/mlp_stamps.py 2>&1 | tail -20) > $O/k7_stamps_v3_M16384.txt
 cd /tmp
 pmc() {  # pmc <variant> <kernel> <out>
   rm -rf $O/pmc_fetch $O/pmc_write

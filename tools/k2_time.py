@@ -1,5 +1,5 @@
 """Stand-alone time of the E = 4 epoch shuffles of one update (B = 524 288) and bit-exactness against numpy;
-AURPPO_K2_ACCEPT=1|2 selects the accept kernel."""
+AURPPO_K2_ACCEPT=1|2|3 selects the accept kernel (default 3)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
