@@ -4,7 +4,10 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
-from aur_ppo_amd import hip_ops as H
+from aur_ppo_amd import _lib, hip_ops as H
+if os.environ.get("AURPPO_LIB"):      # another build of the library (timing experiments)
+    _lib.LIB_PATH = os.environ["AURPPO_LIB"]
+    _lib._lib = None
 B, E = int(os.environ.get("K2_B", 524288)), 4
 rng = H.MT19937(1, B, torch.device("cuda"))
 out = torch.empty((E, B), dtype=torch.int32, device="cuda")
