@@ -69,7 +69,7 @@ def load() -> C.CDLL:
     lib.aurppo_mlp_wide_ppo_step_f32.argtypes = ([vp] * 4 + [i32] * 6 + [vp, C.POINTER(i32), i32, vp, f64, f64, f64, i32, i32] +
                                                  [vp] * 5)
     lib.aurppo_mlp_wide_ppo_minibatch_f32.argtypes = ([vp] * 4 + [i32] * 6 + [vp, C.POINTER(i32), i32, vp, f64, f64, f64, i32, i32] +
-                                                      [vp, vp, vp, f64, vp, vp, f64, f64, f64, vp, vp, vp])
+                                                      [vp, vp, vp, f64, vp, vp, f64, f64, f64, vp, vp, i32, i32, vp, vp])
     lib.aurppo_mlp_wide_act_f32.argtypes = [vp, vp] + [i32] * 6 + [vp, C.POINTER(i32), i32] + [vp] * 5
     lib.aurppo_mlp_workspace_bytes.argtypes = [i32]
     lib.aurppo_mlp_workspace_bytes.restype = C.c_size_t

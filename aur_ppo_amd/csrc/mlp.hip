@@ -317,8 +317,31 @@ struct OperandCopies {
     int w2_actor, w2_critic;
     unsigned short* wop3;
     int w3_actor, w3_critic, A, wop_mode;
+    aurppo_mlp::WideCopies wide;     // K7w's copies (wide.wop == nullptr: none)
 };
 __device__ __forceinline__ void refresh_operand_copies(const OperandCopies& oc, int i, float pn) {
+    if (oc.wide.wop) {
+        // K7w (k_mlpw_prep's layout, source-first): forward copy B[k][j] = W[j][k], backward copy (layers >= 1) B[k][j] = W[k][j];
+        // entry ((nl * 2 + dir) * 16 + blk) * 1024 + lane * 16 + m
+        const aurppo_mlp::WideCopies& wc = oc.wide;
+        for (int n = 0; n < 2; ++n)
+            for (int l = 0; l < wc.NL; ++l) {
+                const int in_dim = l == 0 ? wc.D : wc.Hd;
+                const int e = i - wc.w[n][l];
+                if (e < 0 || e >= wc.Hd * in_dim) continue;
+                const int row = e / in_dim, col = e - row * in_dim;
+                const int nl = n * 3 + l;
+                {
+                    const int blk = (row >> 5) * 4 + (col >> 5), lane = (row & 31) + 32 * (col & 1), m = (col & 31) >> 1;
+                    wc.wop[(((nl * 2 + 0) * 16 + blk) * 64 + lane) * 16 + m] = pn;
+                }
+                if (l > 0) {
+                    const int blk = (col >> 5) * 4 + (row >> 5), lane = (col & 31) + 32 * (row & 1), m = (row & 31) >> 1;
+                    wc.wop[(((nl * 2 + 1) * 16 + blk) * 64 + lane) * 16 + m] = pn;
+                }
+            }
+        return;
+    }
     const int D = oc.D, A = oc.A;
     const int ea = i - oc.w1_actor, ec = i - oc.w1_critic;
     const int e = (ea >= 0 && ea < H * D) ? ea : ((ec >= 0 && ec < H * D) ? ec : -1);
@@ -597,8 +620,9 @@ static int mlp_step_impl(const float* obs, const float* actions, const float* re
         int nb_upd = (n_params + kThreads * 4 - 1) / (kThreads * 4);
         if (nb_upd > 64) nb_upd = 64;
         const int nsb = chain->next_idx ? stat_blocks_for(chain->next_M) : 0;
-        const OperandCopies oc = {a.L.w1[0], a.L.w1[1], D, a.w1op, a.L.w2[0], a.L.w2[1],
-                                  variant >= 3 ? wv.wop3 : (unsigned short*)nullptr, a.L.w3[0], a.L.w3[1], A, variant};
+        OperandCopies oc = {a.L.w1[0], a.L.w1[1], D, a.w1op, a.L.w2[0], a.L.w2[1],
+                            variant >= 3 ? wv.wop3 : (unsigned short*)nullptr, a.L.w3[0], a.L.w3[1], A, variant, {}};
+        oc.wide.wop = nullptr;
         hipLaunchKernelGGL(k_adam_chain, dim3(nb_upd + nsb), dim3(kThreads), 0, s, chain->params_rw, grads, chain->exp_avg,
                            chain->exp_avg_sq, n_params, sq_part, n_red, (float)chain->max_norm, chain->lr_dev,
                            chain->step_dev, chain->beta1, chain->beta2, chain->eps, chain->out_norm, 1.0f, nb_upd, oc,
@@ -610,7 +634,8 @@ static int mlp_step_impl(const float* obs, const float* actions, const float* re
 
 namespace {
 OperandCopies no_operand_copies(int n_params) {   // every offset past the bucket: no copy is refreshed
-    const OperandCopies oc = {n_params, n_params, 1, nullptr, n_params, n_params, nullptr, n_params, n_params, 1, 2};
+    OperandCopies oc = {n_params, n_params, 1, nullptr, n_params, n_params, nullptr, n_params, n_params, 1, 2, {}};
+    oc.wide.wop = nullptr;
     return oc;
 }
 }  // namespace
@@ -633,14 +658,17 @@ int aurppo_mlp::launch_mlp_reduce(const float* slabs, const double* loss_part, i
 
 int aurppo_mlp::launch_adam_tail(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int n_params,
                                  const double* sq_part, double max_norm, const float* lr_dev, const float* step_dev,
-                                 double beta1, double beta2, double eps, float* out_norm, hipStream_t s) {
+                                 double beta1, double beta2, double eps, float* out_norm, hipStream_t s, const WideCopies* wide,
+                                 const float4* rec, int rec_stride, const int32_t* next_idx, int next_M, double* stats) {
     int nb_upd = (n_params + kThreads * 4 - 1) / (kThreads * 4);
     if (nb_upd > 64) nb_upd = 64;
-    // no operand-order copy of W1 (offsets past the bucket), no statistics for a next minibatch
-    hipLaunchKernelGGL(k_adam_chain, dim3(nb_upd), dim3(kThreads), 0, s, params, grads, exp_avg, exp_avg_sq, n_params, sq_part,
-                       (n_params + 63) / 64, (float)max_norm, lr_dev, step_dev, beta1, beta2, eps, out_norm, 1.0f, nb_upd,
-                       no_operand_copies(n_params), (const float4*)nullptr, 1, (const int32_t*)nullptr, 0,
-                       (double (*)[2]) nullptr);
+    // no K7 operand copies (offsets past the bucket); K7w's if the caller names them; statistics of a next minibatch if it names one
+    OperandCopies oc = no_operand_copies(n_params);
+    if (wide) oc.wide = *wide;
+    const int nsb = (next_idx && stats) ? stat_blocks_for(next_M) : 0;
+    hipLaunchKernelGGL(k_adam_chain, dim3(nb_upd + nsb), dim3(kThreads), 0, s, params, grads, exp_avg, exp_avg_sq, n_params, sq_part,
+                       (n_params + 63) / 64, (float)max_norm, lr_dev, step_dev, beta1, beta2, eps, out_norm, 1.0f, nb_upd, oc, rec,
+                       rec_stride, nsb ? next_idx : (const int32_t*)nullptr, nsb ? next_M : 0, reinterpret_cast<double (*)[2]>(stats));
     AURPPO_LAUNCH_CHECK("k_adam_chain");
     return AURPPO_OK;
 }
@@ -716,9 +744,10 @@ extern "C" int aurppo_mlp_ppo_apply_f32(float* params, float* grads, float* exp_
     int nb_upd = (n_params + kThreads * 4 - 1) / (kThreads * 4);
     if (nb_upd > 64) nb_upd = 64;
     const int nsb = next_idx ? stat_blocks_for(next_M) : 0;
-    const OperandCopies oc_apply = {layout_h[0], layout_h[6], D, w1op, layout_h[2], layout_h[8],
-                                    aurppo_knobs().k7_variant >= 3 ? wv.wop3 : (unsigned short*)nullptr, layout_h[4], layout_h[10],
-                                    A_apply, aurppo_knobs().k7_variant};
+    OperandCopies oc_apply = {layout_h[0], layout_h[6], D, w1op, layout_h[2], layout_h[8],
+                              aurppo_knobs().k7_variant >= 3 ? wv.wop3 : (unsigned short*)nullptr, layout_h[4], layout_h[10],
+                              A_apply, aurppo_knobs().k7_variant, {}};
+    oc_apply.wide.wop = nullptr;
     hipLaunchKernelGGL(k_adam_chain, dim3(nb_upd + nsb), dim3(kThreads), 0, (hipStream_t)stream, params, grads, exp_avg,
                        exp_avg_sq, n_params, (const double*)nullptr, 0, (float)max_norm, lr_dev, step_dev, beta1, beta2, eps,
                        out_norm, (float)grad_scale, nb_upd, oc_apply,

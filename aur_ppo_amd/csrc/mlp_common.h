@@ -184,8 +184,17 @@ int launch_mlp_step4(const MlpArgs& a, int grid, hipStream_t s);
 int launch_mlp_reduce(const float* slabs, const double* loss_part, int n_slabs, int n_params, const PpoHyper& h, float* grads,
                       float* out_scalars, hipStream_t s, double* sq_part = nullptr, float* step_dev = nullptr,
                       unsigned* scratch_counter = nullptr);   // (with step_dev: a device word the kernel may clear)
+// K7w's operand-order copies of the hidden layers (mlp_wide.hip: [net][layer][fwd | bwd][4 x 4 blocks][lane][16 k-steps]): where the
+// optimizer launch drops an updated weight so that the next K7w launch needs no prepare pass.  wop == nullptr: nothing to refresh.
+struct WideCopies {
+    int w[2][3];       // float offsets of the hidden layers' weights in the bucket
+    int NL, Hd, D;
+    float* wop;
+};
+// next_idx != nullptr: the launch also forms the next minibatch's advantage partial sums (stats: (kStatBlocks, 2) doubles).
 int launch_adam_tail(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int n_params, const double* sq_part,
                      double max_norm, const float* lr_dev, const float* step_dev, double beta1, double beta2, double eps,
-                     float* out_norm, hipStream_t s);
+                     float* out_norm, hipStream_t s, const WideCopies* wide = nullptr, const float4* rec = nullptr, int rec_stride = 1,
+                     const int32_t* next_idx = nullptr, int next_M = 0, double* stats = nullptr);
 
 }  // namespace aurppo_mlp

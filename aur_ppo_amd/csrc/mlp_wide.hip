@@ -774,6 +774,9 @@ struct WideTail {   // the optimizer half of aurppo_mlp_wide_ppo_minibatch_f32
     float* step_dev;
     double beta1, beta2, eps;
     float* out_norm;
+    const int32_t* next_idx;   // the slice stepped next: its statistics (and the refreshed operand copies) are left by this call
+    int next_M;
+    int chained;               // the previous call named this idx as its next_idx: no prepare pass
 };
 }  // namespace
 
@@ -803,9 +806,11 @@ static int wide_step_impl(const float* obs, const float* actions, const float* r
     int sb = (M + 1023) / 1024;
     if (sb > kStatBlocks) sb = kStatBlocks;
     a.n_stat_blocks = sb;
-    hipLaunchKernelGGL(k_mlpw_prep, dim3(sb + 96), dim3(256), 0, s, params, a.L, num_layers, D, hidden, wv.wop, a.rec,
-                       a.rec_stride, idx, M, reinterpret_cast<double (*)[2]>(wv.stats), sb, wv.tile_counter);
-    AURPPO_LAUNCH_CHECK("k_mlpw_prep");
+    if (!(tail && tail->chained)) {   // otherwise the previous chained call's optimizer launch has left all of this
+        hipLaunchKernelGGL(k_mlpw_prep, dim3(sb + 96), dim3(256), 0, s, params, a.L, num_layers, D, hidden, wv.wop, a.rec,
+                           a.rec_stride, idx, M, reinterpret_cast<double (*)[2]>(wv.stats), sb, wv.tile_counter);
+        AURPPO_LAUNCH_CHECK("k_mlpw_prep");
+    }
     static int cus_of[kMaxDevices] = {0};
     const int dslot = aurppo_device_slot();
     if (!cus_of[dslot]) {
@@ -840,11 +845,17 @@ static int wide_step_impl(const float* obs, const float* actions, const float* r
     AURPPO_LAUNCH_CHECK("k_mlpw_step");
     if (ev_end) AURPPO_HIP_TRY(hipEventRecord((hipEvent_t)ev_end, s));
     if (!tail) return launch_mlp_reduce(wv.slabs, wv.loss_part, pairs, n_params, a.h, grads, out_scalars, s);
+    // (the reduce clears the tile counters for the launch that follows: the next chained call has no prepare pass to do it)
     rc = launch_mlp_reduce(wv.slabs, wv.loss_part, pairs, n_params, a.h, grads, out_scalars, s, wv.sq_part, tail->step_dev,
-                           wv.tile_counter + 8);
+                           wv.tile_counter);
     if (rc != AURPPO_OK) return rc;
+    WideCopies wc;
+    for (int n = 0; n < 2; ++n)
+        for (int l = 0; l < 3; ++l) wc.w[n][l] = l < num_layers ? a.L.w[n][l] : n_params;
+    wc.NL = num_layers; wc.Hd = hidden; wc.D = D; wc.wop = wv.wop;
     return launch_adam_tail(tail->params_rw, grads, tail->exp_avg, tail->exp_avg_sq, n_params, wv.sq_part, tail->max_norm,
-                            tail->lr_dev, tail->step_dev, tail->beta1, tail->beta2, tail->eps, tail->out_norm, s);
+                            tail->lr_dev, tail->step_dev, tail->beta1, tail->beta2, tail->eps, tail->out_norm, s,
+                            tail->next_idx ? &wc : nullptr, a.rec, a.rec_stride, tail->next_idx, tail->next_M, wv.stats);
 }
 
 extern "C" int aurppo_mlp_wide_ppo_step_f32(const float* obs, const float* actions, const float* rec, const int32_t* idx, int M,
@@ -863,12 +874,14 @@ extern "C" int aurppo_mlp_wide_ppo_minibatch_f32(const float* obs, const float* 
                                                  double vf_coef, int norm_adv, int vloss_mode, float* out_scalars,
                                                  float* exp_avg, float* exp_avg_sq, double max_norm, const float* lr_dev,
                                                  float* step_dev, double beta1, double beta2, double eps, float* out_norm,
-                                                 void* workspace, void* stream) {
+                                                 const int32_t* next_idx, int next_M, int chained, void* workspace, void* stream) {
     AURPPO_REQUIRE(exp_avg && exp_avg_sq && lr_dev && step_dev && out_norm, AURPPO_EINVAL,
                    "aurppo_mlp_wide_ppo_minibatch_f32: null optimizer pointer");
+    AURPPO_REQUIRE(!next_idx || next_M > 0, AURPPO_ESHAPE, "aurppo_mlp_wide_ppo_minibatch_f32: next_M=%d", next_M);
     WideTail t;
     t.params_rw = params; t.exp_avg = exp_avg; t.exp_avg_sq = exp_avg_sq; t.max_norm = max_norm; t.lr_dev = lr_dev;
     t.step_dev = step_dev; t.beta1 = beta1; t.beta2 = beta2; t.eps = eps; t.out_norm = out_norm;
+    t.next_idx = next_idx; t.next_M = next_idx ? next_M : 0; t.chained = chained ? 1 : 0;
     return wide_step_impl(obs, actions, rec, idx, M, D, A, continuous, hidden, num_layers, params, layout_h, n_params, grads, clip,
                           ent_coef, vf_coef, norm_adv, vloss_mode, out_scalars, workspace, stream, nullptr, nullptr, &t,
                           "aurppo_mlp_wide_ppo_minibatch_f32");

@@ -424,7 +424,7 @@ def mlp_ppo_step(obs, actions, rec, idx, flat_param, layout, flat_grad, clip, en
 def mlp_ppo_minibatch(obs, actions, rec, idx, flat_param, layout, flat_grad, clip, ent_coef, vf_coef, norm_adv, vloss_mode,
                       out_scalars, exp_avg, exp_avg_sq, lr_dev, step_dev, max_norm, betas, eps, out_norm, next_idx=None,
                       chained=False):
-    """K7 + K6b chained: one whole minibatch (src/ppo.py:219-269) -- fused step, clip_grad_norm_ and Adam over the
+    """K7 (K7w) + K6b chained: one whole minibatch (src/ppo.py:219-269) -- fused step, clip_grad_norm_ and Adam over the
     same flat bucket -- in three launches.  ``next_idx``: the slice stepped next (its statistics are prepared by
     this call); ``chained=True`` when the previous call named this ``idx`` as its ``next_idx``."""
     lib = _lib_or_raise()
@@ -436,14 +436,17 @@ def mlp_ppo_minibatch(obs, actions, rec, idx, flat_param, layout, flat_grad, cli
         raise ValueError("mlp_ppo_minibatch: the flat bucket is smaller than the policy")
     # alignment padding past n_params is left alone: its gradient is never written, so clip and Adam are no-ops there
     if layout.get("wide"):
-        # K7w: prepare + step + slab reduce + clip/Adam, four launches (no hand-over between calls: next_idx / chained unused)
+        # K7w: prepare + step + slab reduce + clip/Adam; with next_idx the optimizer launch leaves the operand copies and the
+        # next slice's statistics, and a chained call then skips its prepare launch
         ws = _workspace("mlp_wide", lib.aurppo_mlp_wide_workspace_bytes(n, layout["hidden"], D), obs.device)
         lay = (C.c_int * len(layout["offsets"]))(*layout["offsets"])
         _check(lib.aurppo_mlp_wide_ppo_minibatch_f32(
             _ptr(obs), _optr(actions), _ptr(rec), _ptr(idx, torch.int32), M, D, A, int(cont), layout["hidden"], layout["num_layers"],
             _ptr(flat_param), lay, n, _ptr(flat_grad), float(clip), float(ent_coef), float(vf_coef), int(bool(norm_adv)),
             int(vloss_mode), _ptr(out_scalars), _ptr(exp_avg), _ptr(exp_avg_sq), float(max_norm), _ptr(lr_dev), _ptr(step_dev),
-            float(betas[0]), float(betas[1]), float(eps), _ptr(out_norm), C.c_void_p(ws.data_ptr()), _stream()),
+            float(betas[0]), float(betas[1]), float(eps), _ptr(out_norm),
+            _ptr(next_idx, torch.int32) if next_idx is not None else None, int(next_idx.numel()) if next_idx is not None else 0,
+            int(bool(chained)), C.c_void_p(ws.data_ptr()), _stream()),
             "aurppo_mlp_wide_ppo_minibatch_f32")
         return out_scalars
     ws = _workspace("mlp", lib.aurppo_mlp_workspace_bytes(n), obs.device)

@@ -255,14 +255,17 @@ int aurppo_mlp_wide_ppo_step_f32(const float* obs, const float* actions, const f
                                  void* stream, void* ev_begin, void* ev_end);
 /* The step chained with clip_grad_norm_ + Adam.step over the same flat bucket (src/ppo.py:219-269 for one minibatch), as
  * aurppo_mlp_ppo_minibatch_f32 is for the default shape -- four launches (prepare, step, slab reduce that also leaves
- * the clip's partial sums and advances the step count, clip + Adam).  Single process only.                             */
+ * the clip's partial sums and advances the step count, clip + Adam).  next_idx / next_M: the index slice the NEXT call
+ * will step (NULL: none) -- the optimizer launch then also drops every updated weight into the operand-order copies and
+ * forms that slice's advantage statistics; chained != 0: the previous call named this idx as its next_idx, so this call
+ * has no prepare launch (three launches).  Single process only.                                                        */
 int aurppo_mlp_wide_ppo_minibatch_f32(const float* obs, const float* actions, const float* rec, const int32_t* idx,
                                       int M, int D, int A, int continuous, int hidden, int num_layers, float* params,
                                       const int* layout_h, int n_params, float* grads, double clip, double ent_coef,
                                       double vf_coef, int norm_adv, int vloss_mode, float* out_scalars,
                                       float* exp_avg, float* exp_avg_sq, double max_norm, const float* lr_dev,
                                       float* step_dev, double beta1, double beta2, double eps, float* out_norm,
-                                      void* workspace, void* stream);
+                                      const int32_t* next_idx, int next_M, int chained, void* workspace, void* stream);
 int aurppo_mlp_wide_act_f32(const float* obs, const float* noise, int N, int D, int A, int continuous, int hidden,
                             int num_layers, const float* params, const int* layout_h, int n_params, float* actions,
                             float* logp, float* value, void* workspace, void* stream);

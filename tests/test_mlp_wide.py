@@ -216,8 +216,9 @@ def test_rollout_with_a_wide_policy_goes_through_k8w_and_trains():
     assert torch.isfinite(a.bucket.flat_param).all()
 
 
-@pytest.mark.parametrize("hidden,layers,D", [(128, 3, 64), (64, 3, 24), (32, 1, 8)])
-def test_wide_minibatch_matches_step_then_clip_adam(hidden, layers, D, monkeypatch):
+@pytest.mark.parametrize("handover", [False, True], ids=["prepare-each-call", "handed-over"])
+@pytest.mark.parametrize("hidden,layers,D", [(128, 3, 64), (64, 3, 24), (32, 1, 8), (96, 2, 100)])
+def test_wide_minibatch_matches_step_then_clip_adam(hidden, layers, D, handover, monkeypatch):
     """aurppo_mlp_wide_ppo_minibatch_f32 over a run of minibatches == the same run as aurppo_mlp_wide_ppo_step_f32 +
     aurppo_clip_adam_f32 pairs: parameters, moments, loss scalars, norms and the Adam step count.  Tiles are dealt by
     static stride in both runs, so the two see the same summation order (tests/test_determinism.py) and the norms can be held
@@ -239,11 +240,15 @@ def test_wide_minibatch_matches_step_then_clip_adam(hidden, layers, D, monkeypat
         norms = torch.zeros(len(slices) * 2, device="cuda")
         g = torch.zeros(nb, device="cuda")
         k = 0
+        seq = slices + slices
         for _rep in range(2):
             for idx in slices:
                 if chained:
+                    # handed-over: every call names the slice stepped next (the optimizer launch refreshes the operand-order
+                    # copies and forms that slice's statistics) and all but the first skip their prepare launch
+                    nxt = seq[k + 1] if (handover and k + 1 < len(seq)) else None
                     H.mlp_ppo_minibatch(obs, act, rec, idx, bucket.flat_param, lay, g, 0.2, 0.01, 0.5, True, 1, sc[k], m, v, lr, t,
-                                        0.5, (0.9, 0.999), 1e-5, norms[k:k + 1])
+                                        0.5, (0.9, 0.999), 1e-5, norms[k:k + 1], next_idx=nxt, chained=handover and k > 0)
                 else:
                     H.mlp_ppo_step(obs, act, rec, idx, bucket.flat_param, lay, g, 0.2, 0.01, 0.5, True, 1, sc[k])
                     H.clip_adam_(bucket.flat_param, g, m, v, lr, t, 0.5, None, (0.9, 0.999), 1e-5, norms[k:k + 1])
