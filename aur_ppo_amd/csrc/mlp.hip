@@ -42,11 +42,7 @@ __global__ __launch_bounds__(256) void k_adv_stats_idx(const float4* __restrict_
         }
     }
     double s = 0.0, q = 0.0;
-    for (int i = blockIdx.x * kThreads + threadIdx.x; i < M; i += gridDim.x * kThreads) {
-        const double a = (double)rec[(size_t)idx[i] * rec_stride].y;
-        s += a;
-        q += a * a;
-    }
+    adv_partial_sums(rec, rec_stride, idx, M, blockIdx.x * kThreads + threadIdx.x, gridDim.x * kThreads, s, q);
     const double bs = block_sum<kThreads / kWave>(s, sc[0]);
     const double bq = block_sum<kThreads / kWave>(q, sc[1]);
     if (threadIdx.x == 0) {
@@ -456,11 +452,7 @@ __global__ __launch_bounds__(kThreads) void k_adam_chain(float* __restrict__ p, 
     } else {
         const int nsb = gridDim.x - nb_upd, b = blockIdx.x - nb_upd;
         double s = 0.0, q = 0.0;
-        for (int i = b * kThreads + threadIdx.x; i < next_M; i += nsb * kThreads) {
-            const double x = (double)rec[(size_t)next_idx[i] * rec_stride].y;
-            s += x;
-            q += x * x;
-        }
+        adv_partial_sums(rec, rec_stride, next_idx, next_M, b * kThreads + threadIdx.x, nsb * kThreads, s, q);
         const double bs = block_sum<kThreads / kWave>(s, sc[0]);
         const double bq = block_sum<kThreads / kWave>(q, sc[1]);
         if (threadIdx.x == 0) {

@@ -184,6 +184,28 @@ int launch_mlp_step4(const MlpArgs& a, int grid, hipStream_t s);
 int launch_mlp_reduce(const float* slabs, const double* loss_part, int n_slabs, int n_params, const PpoHyper& h, float* grads,
                       float* out_scalars, hipStream_t s, double* sq_part = nullptr, float* step_dev = nullptr,
                       unsigned* scratch_counter = nullptr);   // (with step_dev: a device word the kernel may clear)
+// One thread's share of a minibatch's advantage partial sums: elements first, first + step, ... in that order (the sums are the
+// same bits as the plain loop's), four index loads and then four record loads in flight at a time -- the plain loop paid two
+// dependent memory round trips per element.
+__device__ __forceinline__ void adv_partial_sums(const float4* __restrict__ rec, int rec_stride, const int32_t* __restrict__ idx,
+                                                 int M, int first, int step, double& s, double& q) {
+    int i = first;
+    for (; i + 3 * step < M; i += 4 * step) {
+        const int j0 = idx[i], j1 = idx[i + step], j2 = idx[i + 2 * step], j3 = idx[i + 3 * step];
+        const float x0 = rec[(size_t)j0 * rec_stride].y, x1 = rec[(size_t)j1 * rec_stride].y;
+        const float x2 = rec[(size_t)j2 * rec_stride].y, x3 = rec[(size_t)j3 * rec_stride].y;
+        s += (double)x0; q += (double)x0 * (double)x0;
+        s += (double)x1; q += (double)x1 * (double)x1;
+        s += (double)x2; q += (double)x2 * (double)x2;
+        s += (double)x3; q += (double)x3 * (double)x3;
+    }
+    for (; i < M; i += step) {
+        const double x = (double)rec[(size_t)idx[i] * rec_stride].y;
+        s += x;
+        q += x * x;
+    }
+}
+
 // K7w's operand-order copies of the hidden layers (mlp_wide.hip: [net][layer][fwd | bwd][4 x 4 blocks][lane][16 k-steps]): where the
 // optimizer launch drops an updated weight so that the next K7w launch needs no prepare pass.  wop == nullptr: nothing to refresh.
 struct WideCopies {

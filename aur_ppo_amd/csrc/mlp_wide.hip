@@ -77,11 +77,7 @@ __global__ __launch_bounds__(256) void k_mlpw_prep(const float* __restrict__ par
     if (tile_counter && blockIdx.x == 0 && threadIdx.x < 2) tile_counter[threadIdx.x] = 0u;
     if ((int)blockIdx.x < n_stat_blocks) {
         double s = 0.0, q = 0.0;
-        for (int i = blockIdx.x * 256 + threadIdx.x; i < M; i += n_stat_blocks * 256) {
-            const double a = (double)rec[(size_t)idx[i] * rec_stride].y;
-            s += a;
-            q += a * a;
-        }
+        adv_partial_sums(rec, rec_stride, idx, M, blockIdx.x * 256 + threadIdx.x, n_stat_blocks * 256, s, q);
         const double bs = block_sum<4>(s, sc[0]);
         const double bq = block_sum<4>(q, sc[1]);
         if (threadIdx.x == 0) {
