@@ -58,7 +58,6 @@ struct AurppoKnobs {
     int k2_post_stream;    // AURPPO_K2_POST_STREAM: 1 (default since round 3) = link + resolve on a third stream of the handle; 0 = behind accept / fill
     int k2_accept3_wgs;    // AURPPO_K2_ACCEPT3_WGS: workgroups of k_fy_accept3's relay (default 6)
     int k2_accept;         // AURPPO_K2_ACCEPT: 1 = k_fy_accept (workgroup rounds, default), 2 = k_fy_accept2 (wave relay; bit-exact, measured slower), 3 = k_fy_accept3 (workgroup relay)
-    int k2_fill_wgs;       // AURPPO_K2_FILL_WGS: workgroups of the parallel twist (default: see shuffle.hip; 1 = the serial twist)
     int gather_unroll;     // AURPPO_GATHER_UNROLL (0 = by row width)
     int gather_rows;       // AURPPO_GATHER_ROWS (0 = by row width)
 };

@@ -61,11 +61,7 @@ static_assert(2 * kPersist * kWave * 4 <= oTab, "hand-over scratch must fit the 
 // lane's byte offset: one scalar base per block + a 32-bit vector offset + an immediate per plane, instead of ninety 64-bit
 // vector addresses that would be formed once, hoisted out of the tile loop and spilled.
 __device__ __forceinline__ Frag3 w_frag(const char* wnet, int id, int lane16) {
-#ifdef AURPPO_V4_HACK_SAMEBLOCK      // timing experiment only (wrong results): every weight fragment from block 0, i.e. from L1
-    const char* blk = wnet + (id & 1) * (3 * 1024);
-#else
     const char* blk = wnet + id * (3 * 1024);
-#endif
     Frag3 f;
     f.p[0] = *reinterpret_cast<const bf16x8*>(blk + lane16);
     f.p[1] = *reinterpret_cast<const bf16x8*>(blk + 1024 + lane16);
