@@ -31,6 +31,7 @@ AurppoKnobs parse_knobs() {
     k.k2_post_stream = env_int("AURPPO_K2_POST_STREAM", 1);
     k.k2_accept = env_int("AURPPO_K2_ACCEPT", 3);
     k.k2_accept3_wgs = env_int("AURPPO_K2_ACCEPT3_WGS", 6);
+    k.k2_starve = env_int("AURPPO_TEST_K2_STARVE", 0);
     k.gather_unroll = env_int("AURPPO_GATHER_UNROLL", 0);
     k.gather_rows = env_int("AURPPO_GATHER_ROWS", 0);
     return k;

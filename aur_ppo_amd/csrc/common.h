@@ -56,6 +56,7 @@ struct AurppoKnobs {
     int k2_link_wgs;       // AURPPO_K2_LINK_WGS: workgroups of k_fy_link (default 48; 0 = one per 256 positions)
     int k2_resolve_wgs;    // AURPPO_K2_RESOLVE_WGS: workgroups of k_fy_resolve (default 256; 0 = one per 256 positions)
     int k2_post_stream;    // AURPPO_K2_POST_STREAM: 1 (default since round 3) = link + resolve on a third stream of the handle; 0 = behind accept / fill
+    int k2_starve;         // AURPPO_TEST_K2_STARVE (tests): the twist keeps this per cent of one shuffle's draws in stock, so shuffles run dry
     int k2_accept3_wgs;    // AURPPO_K2_ACCEPT3_WGS: workgroups of k_fy_accept3's relay (default 6)
     int k2_accept;         // AURPPO_K2_ACCEPT: 1 = k_fy_accept (workgroup rounds, default), 2 = k_fy_accept2 (wave relay; bit-exact, measured slower), 3 = k_fy_accept3 (workgroup relay)
     int gather_unroll;     // AURPPO_GATHER_UNROLL (0 = by row width)

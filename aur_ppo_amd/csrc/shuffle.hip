@@ -1211,7 +1211,7 @@ __global__ __launch_bounds__(kAccThreads) void k_fy_accept3(const uint32_t* __re
 // (It was a memset between accept and link: 5 us of work that had to find a free CU beside K7, ~100 us in-situ; as
 // stores inside the single-workgroup accept kernel it cost that kernel 20-40 us.)
 __global__ void k_fy_link(const int32_t* __restrict__ j, int32_t* __restrict__ head, int32_t* __restrict__ next,
-                          int n, int32_t* __restrict__ clr, int clr_n) {
+                          int n, int32_t* __restrict__ clr, int clr_n, const long long* __restrict__ posv) {
     // grid-stride, four positions per pass: their swaps are in flight together (a memory-side atomic takes ~1 us)
     constexpr int kB = 4;
     const int stride = gridDim.x * blockDim.x;
@@ -1221,6 +1221,8 @@ __global__ void k_fy_link(const int32_t* __restrict__ j, int32_t* __restrict__ h
         i32x4* dst = reinterpret_cast<i32x4*>(clr);
         for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < clr_n / 4; q += stride) dst[q] = m1;
     }
+    // a shuffle that ran out of draws (sticky flag) left targets unwritten: nothing may be indexed with them
+    if (posv[2] != 0) return;
     for (int s0 = blockIdx.x * blockDim.x + threadIdx.x; s0 < n; s0 += kB * stride) {
         int js[kB], old[kB];
 #pragma unroll
@@ -1244,10 +1246,15 @@ __global__ void k_fy_link(const int32_t* __restrict__ j, int32_t* __restrict__ h
 // out[i] = in[src(i)] (in == nullptr: identity), src(i) = position whose ORIGINAL content ends at i.
 __global__ void k_fy_resolve(const int32_t* __restrict__ j, const int32_t* __restrict__ head,
                              const int32_t* __restrict__ next, const int32_t* __restrict__ in,
-                             int32_t* __restrict__ out, int n) {
+                             int32_t* __restrict__ out, int n, const long long* __restrict__ posv) {
   // grid-stride: a bounded grid (AURPPO_K2_RESOLVE_WGS) keeps the kernel on the few CUs K7 leaves free instead of queueing
   // thousands of short workgroups behind it
+  const bool broken = posv[2] != 0;   // the shuffle ran out of draws: hand back the input order (valid indices; the flag says it is not a shuffle)
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    if (broken) {
+        out[i] = in ? in[i] : i;
+        continue;
+    }
     const int kNone = 0x7fffffff;
     int src;
     int cur = i;
@@ -1354,6 +1361,13 @@ static hipStream_t fill_stream_of(aurppo_rng* rng, hipStream_t s) {
     return aurppo_knobs().k2_one_stream == 1 ? s : rng->fill_stream;
 }
 
+// Inventory the twist is asked to keep: two shuffles' worth.  Diagnostic knob AURPPO_TEST_K2_STARVE=p (tests only): p per cent
+// of ONE shuffle's need instead, so that a shuffle runs out of draws -- the sticky-error path no real run reaches (12 sigma).
+static long long fill_target(double need) {
+    const int starve = aurppo_knobs().k2_starve;
+    return (long long)(starve > 0 ? need * (double)starve / 100.0 : 2.0 * need);
+}
+
 static int enqueue_fill(aurppo_rng* rng, double need, hipStream_t after, int slot, int cur_slot) {
     const hipStream_t fs = fill_stream_of(rng, after);
     // inventory target 2*need: one shuffle may be consuming while the next one's draws are produced
@@ -1362,7 +1376,7 @@ static int enqueue_fill(aurppo_rng* rng, double need, hipStream_t after, int slo
     const int nblk_max = (int)(2.0 * need / kMtN) + 2;
     AURPPO_HIP_TRY(own_cu_setup());
     hipLaunchKernelGGL(k_mt_fill, dim3(1), dim3(kFillAll), kOwnCuLds, fs, rng->d_last, rng->d_ring,
-                       (long long)rng->ring_cap, rng->d_pos, (long long)(2.0 * need), nblk_max, cur_slot);
+                       (long long)rng->ring_cap, rng->d_pos, fill_target(need), nblk_max, cur_slot);
     AURPPO_LAUNCH_CHECK("k_mt_fill");
     AURPPO_HIP_TRY(hipEventRecord(rng->ev_fill[slot], fs));
     return AURPPO_OK;
@@ -1430,7 +1444,7 @@ int permute_once(aurppo_rng* rng, const int32_t* in, int32_t* out, int n, hipStr
     const int link_wgs = aurppo_knobs().k2_link_wgs;
     if (rng->use_post) AURPPO_HIP_TRY(hipStreamWaitEvent(ls, rng->ev_acc[slot], 0));
     hipLaunchKernelGGL(k_fy_link, dim3(link_wgs > 0 && link_wgs < grid ? link_wgs : grid), dim3(256), 0, ls, rng->d_j[slot],
-                       rng->d_head[h], rng->d_next[slot], n, rng->d_head[hn], clr_n);
+                       rng->d_head[h], rng->d_next[slot], n, rng->d_head[hn], clr_n, rng->d_pos);
     AURPPO_LAUNCH_CHECK("k_fy_link");
     AURPPO_HIP_TRY(hipEventRecord(rng->ev_link[slot], ls));
     // Fill stream, in this order: the NEXT shuffle's draws (assumed the same size; ordered after the PREVIOUS accept,
@@ -1442,7 +1456,7 @@ int permute_once(aurppo_rng* rng, const int32_t* in, int32_t* out, int n, hipStr
     {
         const int nblk_max = (int)(2.0 * need / kMtN) + 2;
         hipLaunchKernelGGL(k_mt_fill, dim3(1), dim3(kFillAll), kOwnCuLds, fs, rng->d_last, rng->d_ring,
-                           (long long)rng->ring_cap, rng->d_pos, (long long)(2.0 * need), nblk_max,
+                           (long long)rng->ring_cap, rng->d_pos, fill_target(need), nblk_max,
                            rng->seq > 0 ? 4 + (slot ^ 1) : 1);   // cursor after the PREVIOUS shuffle (done: waited above)
         AURPPO_LAUNCH_CHECK("k_mt_fill");
         AURPPO_HIP_TRY(hipEventRecord(rng->ev_fill[slot ^ 1], fs));
@@ -1455,7 +1469,7 @@ int permute_once(aurppo_rng* rng, const int32_t* in, int32_t* out, int n, hipStr
     // / -0.9 % (slack 0.17 ms) / -0.6 % (0.28 ms) / -0.6 % (0.37 ms), alternating runs on one box.
     const int resolve_wgs = aurppo_knobs().k2_resolve_wgs;
     hipLaunchKernelGGL(k_fy_resolve, dim3(resolve_wgs > 0 && resolve_wgs < grid ? resolve_wgs : grid), dim3(256), 0, rs,
-                       rng->d_j[slot], rng->d_head[h], rng->d_next[slot], in, out, n);
+                       rng->d_j[slot], rng->d_head[h], rng->d_next[slot], in, out, n, rng->d_pos);
     AURPPO_LAUNCH_CHECK("k_fy_resolve");
     AURPPO_HIP_TRY(hipEventRecord(rng->ev_res, rs));
     if (rng->use_post) AURPPO_HIP_TRY(hipEventRecord(rng->ev_post[slot], rs));

@@ -182,6 +182,32 @@ def test_shuffle_every_accept_kernel_matches_numpy(H, accept, wgs, monkeypatch):
         assert float(status) == 0.0
 
 
+@pytest.mark.parametrize("accept", ["1", "2", "3"])
+def test_shuffle_that_runs_out_of_draws_raises_the_sticky_flag_and_reseeding_recovers(H, accept, monkeypatch):
+    """np.random.shuffle cannot fail; the device twin works from pre-generated draws (expectation + 12 sigma) and says so if a
+    shuffle ever needs more: every accept kernel must then stop (no hang: the relay's workgroups leave on the `done` word), raise
+    the flag aurppo_mt19937_status_f32 reports, and a reseed must clear it.  AURPPO_TEST_K2_STARVE makes the twist keep 60 % of
+    one shuffle's draws in stock."""
+    monkeypatch.setenv("AURPPO_K2_ACCEPT", accept)
+    n = 200000
+    monkeypatch.setenv("AURPPO_TEST_K2_STARVE", "60")
+    rng = H.MT19937(3, n)
+    rng.shuffle_epochs(n, 2)
+    status = torch.zeros(1, device="cuda")
+    rng.status_into(status)
+    torch.cuda.synchronize()
+    assert float(status) == 1.0
+    monkeypatch.delenv("AURPPO_TEST_K2_STARVE")
+    rng.seed(3)
+    got = rng.shuffle_epochs(n, 1).cpu().numpy()[0]
+    rs = np.random.RandomState(3)
+    idx = np.arange(n)
+    rs.shuffle(idx)
+    np.testing.assert_array_equal(got, idx)
+    rng.status_into(status)
+    assert float(status) == 0.0
+
+
 def test_shuffle_state_roundtrip_and_reseed(H):
     rng = H.MT19937(5, 1000)
     a = rng.shuffle_epochs(1000, 1).clone()
