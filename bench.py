@@ -365,7 +365,7 @@ def run_workload(args, rank, world, dev, envs_per_gpu, steps, warmup, with_probe
         if with_probe and probe.on and not args.no_probe and step_no[0] % every == 1:
             # The update replays as a hipGraph, whose kernels cannot carry readable events: every `every`-th
             # step, time ONE extra stand-alone launch of the dominant kernel on the update's own inputs
-            # (it sits inside the timed region: 150 us per ten 2.7 ms steps).
+            # (it sits inside the timed region: one more ~125 us launch per five / ten 2.2 ms steps, 1.1 % / 0.6 % of `value`).
             if agent._mlp is not None:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 agent.probe_mlp_step(ev)       # events recorded inside the library, around the step kernel only
