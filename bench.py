@@ -499,6 +499,9 @@ def main():
         k = min(len(perm_events), len(side))
         busy = [a.elapsed_time(b) for a, b in perm_events[:k]]
         slack = [pe[1].elapsed_time(me) for pe, me in zip(perm_events[:k], side[:k])]
+        if os.environ.get("AURPPO_BENCH_STEPTIMES"):     # diagnostic: every update's end-to-end interval on the main stream
+            log("main-stream interval per update (ms): " + " ".join(f"{side[i].elapsed_time(side[i + 1]):.3f}" for i in range(len(side) - 1)))
+            log("shuffle busy per update (ms): " + " ".join(f"{x:.3f}" for x in busy))
         side_stream = {"k2_period_ms": round(float(np.median(busy)), 4), "slack_ms": round(float(np.median(slack)), 4),
                        "main_period_ms": round(ms_step, 4),
                        "how": "HIP events on the shuffle side stream (start/end of each update's E shuffles) and on the main "
