@@ -399,8 +399,11 @@ def run_workload(args, rank, world, dev, envs_per_gpu, steps, warmup, with_probe
     D.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    host_ms = []
     for _ in range(steps):
+        th = time.perf_counter()
         one_step()
+        host_ms.append((time.perf_counter() - th) * 1e3)
         if agent._perm_events is not None:          # when did the main stream finish this update?
             e = torch.cuda.Event(enable_timing=True)
             e.record()
@@ -411,6 +414,8 @@ def run_workload(args, rank, world, dev, envs_per_gpu, steps, warmup, with_probe
     probe.on = False
     perm_events, agent._perm_events = agent._perm_events, None
     log(f"{envs_per_gpu} envs/GPU: timed region {dt:.3f} s for {steps} steps")
+    if os.environ.get("AURPPO_BENCH_STEPTIMES"):     # diagnostic: how long the host took to ENQUEUE each update (nothing waits in there)
+        log("host enqueue time per update (ms): " + " ".join(f"{x:.3f}" for x in host_ms))
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
