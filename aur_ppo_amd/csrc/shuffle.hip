@@ -9,8 +9,9 @@
 // split into the part that is inherently a stream and the part that is not:
 //   1a. k_mt_fill -- one workgroup runs the twist only, as 227-word phases of the recurrence
 //      x[m] = x[m-227] ^ mix(x[m-624], x[m-623]): a lane owns one offset of every phase (x[m-227] is its own previous
-//      output, a register), two phases share a barrier, and four helper waves temper and store the words to a ring in
-//      HBM one barrier behind the four that twist.  It runs one shuffle ahead of its consumer on the handle's own stream.
+//      output, a register), two phases share a barrier, and eight helper waves store the words -- UNTEMPERED: the consumers
+//      temper what they read -- to a ring in HBM one barrier behind the four that twist.  It runs one shuffle ahead of its
+//      consumer on the handle's own stream.
 //   1b. k_fy_accept3 (default; k_fy_accept / k_fy_accept2 are the one-workgroup builds it grew from) -- turns the draws into
 //      accept/reject decisions.  Whether draw p is accepted depends on the index i it is tried against, i.e. on how
 //      many earlier draws were accepted -- a triangular system.  A thread resolves its own consecutive draws exactly
@@ -87,18 +88,6 @@ __global__ void k_mt_seed(uint32_t* state, uint32_t seed) {
     state[kMtN] = kMtN;  // pos: next draw regenerates
 }
 
-__device__ __forceinline__ uint32_t mt_untemper(uint32_t y) {
-    y ^= y >> 18;
-    y ^= (y << 15) & 0xefc60000u;
-    uint32_t t = y;                       // invert y ^= (y << 7) & 0x9d2c5680
-    for (int k = 0; k < 4; ++k) t = y ^ ((t << 7) & 0x9d2c5680u);
-    y = t;
-    t = y;                                // invert y ^= y >> 11
-    t = y ^ (t >> 11);
-    t = y ^ (t >> 11);
-    return t;
-}
-
 constexpr int kFillThreads = 256;
 // The first kRingMirror words of the ring are repeated after its end, so a reader may take up to kRingMirror
 // consecutive words from any slot with one straight (vector) access.
@@ -111,23 +100,28 @@ constexpr int kRingMirror = 64;
 // t owning offset t of EVERY phase, the x[m-227] term is the thread's own previous output -- a register.  The two
 // other inputs were written at least two phases earlier, so they come from a small circular window in LDS.  What is
 // left on the critical path of a phase is one XOR, one LDS write and the barrier that publishes it -- and two phases
-// share one barrier (below); tempering and the (coalesced) ring store hang off the side.  The block formulation
+// share one barrier (below); the (coalesced) ring store hangs off the side.  The block formulation
 // this replaces needed three barrier-separated passes with an LDS round trip each per 624 words.
 constexpr int kFillWin = 2048;   // LDS window over the untempered stream (power of two, >= 624 + 2 * 454)
 constexpr int kFillProd = 256;   // waves 0-3: the twist (227 lanes carry a word each)
-constexpr int kFillAll = 768;    // waves 4-11: tempering + ring stores of the pair produced one barrier earlier
+#ifndef AURPPO_FILL_ALL
+#define AURPPO_FILL_ALL 768
+#endif
+constexpr int kFillAll = AURPPO_FILL_ALL;    // waves 4..: ring stores of the pair produced one barrier earlier (768: eight waves, a word each)
 constexpr int kPair = 2 * kMtD;  // words per barrier interval
 
 // Roles.  What a barrier interval must contain is: LDS reads of the mix inputs -> two XORs -> LDS writes -> barrier.
-// Everything else a word needs (tempering: 13 VALU ops, the ring slot arithmetic, the global store and the mirrored
-// head) is off that chain: the producer waves hand the untempered pair to four more waves of the same workgroup
-// through the LDS window they write anyway, and those temper and store it during the NEXT interval, in the issue
-// slots the producers leave free while they wait for LDS.  (First version: every lane tempered and stored its own
+// Everything else a word needs (the ring slot arithmetic, the global store and the mirrored head; until round 3 also the
+// tempering, 13 VALU ops) is off that chain: the producer waves hand the untempered pair to more waves of the same workgroup
+// through the LDS window they write anyway, and those store it during the NEXT interval, in the issue slots the producers
+// leave free while they wait for LDS.  (First version: every lane tempered and stored its own
 // words between the LDS writes and the barrier -- ~95 instructions per wave on the chain, 750 cycles per interval.
 // With four helper waves taking two words each, one after the other, the helpers were the last to reach the barrier:
-// eight of them take one word each.  Round 3 tried the ring UNTEMPERED -- four waves only, each lane storing its own two words
-// behind the barrier, the consumers tempering what they read: 429 us per shuffle's draws against 360, the stores' address
-// arithmetic and exec branches being back on the chain.)
+// eight of them take one word each.  Round 3: twelve waves share four SIMDs, and the helpers' instructions -- not the barrier --
+// paced the interval (three phases per barrier with fifteen waves: 411 us per shuffle's draws against 360; four or two helper
+// waves taking two / four words each: 1.7x / 2.6x slower).  So the tempering moved to the CONSUMERS (k_fy_accept*: 13 more
+// operations per draw on six CUs) and the helpers only store: 319 us.  Without helpers at all -- each producer lane storing its
+// own two words behind the barrier -- it was 429 us: the stores' address arithmetic and exec branches back on the chain.)
 __global__ __launch_bounds__(kFillAll) void k_mt_fill(uint32_t* __restrict__ last, uint32_t* __restrict__ ring,
                                                       long long ring_cap, long long* __restrict__ posv,
                                                       long long target, int nblk_max, int cur_slot) {
@@ -174,16 +168,20 @@ __global__ __launch_bounds__(kFillAll) void k_mt_fill(uint32_t* __restrict__ las
             b1 = win[(m - kMtM + 1) & (kFillWin - 1)];
         }
     } else {
-        const int c = tid - kFillProd;                              // word c of a pair (lanes 454.. idle)
+        constexpr int kHelp = kFillAll - kFillProd;                 // helper lanes; each takes words c, c + kHelp, ... of a pair
+        const int c0 = tid - kFillProd;
         for (int pr = 0; pr <= npair; ++pr) {
             if (pr > 0) {
-                const int w = kMtN + (pr - 1) * kPair + c;          // in the pair finished one barrier ago
-                const uint32_t t = mt_temper(win[w & (kFillWin - 1)]);
-                int at = at0 + (w - kMtN);
-                at -= at >= cap ? cap : 0;
-                if (c < kPair && w < m_end) {
-                    ring[at] = t;
-                    if (at < kRingMirror) ring[cap + at] = t;
+#pragma unroll
+                for (int c = c0; c < kPair; c += kHelp) {
+                    const int w = kMtN + (pr - 1) * kPair + c;      // in the pair finished one barrier ago
+                    const uint32_t t = win[w & (kFillWin - 1)];     // untempered: the consumers temper what they read
+                    int at = at0 + (w - kMtN);
+                    at -= at >= cap ? cap : 0;
+                    if (w < m_end) {
+                        ring[at] = t;
+                        if (at < kRingMirror) ring[cap + at] = t;
+                    }
                 }
             }
             if (pr < npair) __syncthreads();
@@ -203,7 +201,7 @@ __global__ __launch_bounds__(kFillThreads) void k_mt_origin(const uint32_t* __re
     for (int k = tid; k < kMtN; k += kFillThreads) {
         last[k] = state[k];
         if (k >= pos) {
-            const uint32_t t = mt_temper(state[k]);
+            const uint32_t t = state[k];
             ring[k - pos] = t;
             if (k - pos < kRingMirror) ring[ring_cap + (k - pos)] = t;
         }
@@ -234,7 +232,7 @@ __global__ __launch_bounds__(kFillThreads) void k_state_at_cursor(const uint32_t
         pos = kMtN;
     }
     for (int k = tid; k < kMtN; k += kFillThreads)
-        out[k] = blk > 0 ? mt_untemper(ring[(blk * kMtN - pos0 + k) % ring_cap]) : state[k];
+        out[k] = blk > 0 ? ring[(blk * kMtN - pos0 + k) % ring_cap] : state[k];
     if (tid == 0) out[kMtN] = (uint32_t)pos;
 }
 
@@ -332,7 +330,7 @@ __global__ __launch_bounds__(kAccThreads) void k_fy_accept(const uint32_t* __res
         int nhave = 0;                             // my draws that exist (a prefix of the kWpt)
 #pragma unroll
         for (int u = 0; u < kWpt; ++u) {
-            y[u] = ynext[u];
+            y[u] = mt_temper(ynext[u]);     // the ring holds the untempered words
             nhave += (base + u) < avail ? 1 : 0;
         }
         ASTAMP(0);   // draws of this step in registers (waits for the fetch issued one step ago)
@@ -551,7 +549,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_fy_accept2(const uint32_t* __re
         int nhave = 0;                                // my draws that exist (a prefix of the kWpt)
 #pragma unroll
         for (int u = 0; u < kWpt; ++u) {
-            y[u] = ynext[u];
+            y[u] = mt_temper(ynext[u]);     // the ring holds the untempered words
             nhave += (cbase + (long long)lane * kWpt + u) < avail ? 1 : 0;
         }
         fetch(c + kWaves);
@@ -845,7 +843,7 @@ __global__ __launch_bounds__(kAccThreads) void k_fy_accept3(const uint32_t* __re
         int nhave = 0;                                // my draws that exist (a prefix of the kWpt)
 #pragma unroll
         for (int u = 0; u < kWpt; ++u) {
-            y[u] = ynext[u];
+            y[u] = mt_temper(ynext[u]);     // the ring holds the untempered words
             nhave += (cbase + (long long)tid * kWpt + u) < avail ? 1 : 0;
         }
         fetch();
@@ -1342,6 +1340,7 @@ static hipError_t own_cu_setup() {
     if (done) return hipSuccess;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mt_fill), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)kOwnCuLds);
+
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fy_accept<1024, kAccWpt>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kOwnCuLds);
