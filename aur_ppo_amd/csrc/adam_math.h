@@ -17,15 +17,18 @@ template <int NW>
 __device__ __forceinline__ AdamScalars adam_scalars(const double* __restrict__ part, int n_part, float max_norm,
                                                     const float* __restrict__ lr_dev, const float* __restrict__ step,
                                                     double beta1, double beta2, double eps, float* __restrict__ out_norm,
-                                                    bool write_norm, double* sc, float* s_coef) {
+                                                    bool write_norm, double* sc, float* s_coef,
+                                                    const double* __restrict__ bc = nullptr) {
     // the step count and the learning rate are fetched, and the bias corrections formed, while the partial sums are
     // still on their way: one memory round trip for the whole preamble instead of two
     const double tt = (double)*step;
     const double lr = (double)*lr_dev;
     double q = 0.0;
     for (int b = threadIdx.x; b < n_part; b += blockDim.x) q += part[b];
-    const double bc1 = 1.0 - pow(beta1, tt);
-    const double bc2 = 1.0 - pow(beta2, tt);
+    // bc != nullptr: {1 - beta1^t, 1 - beta2^t} were formed by the launch that advanced t (k_mlp_reduce, one thread, beside its
+    // slab loads): two double-precision pow() calls are the longest thing on this kernel's path otherwise
+    const double bc1 = bc ? bc[0] : 1.0 - pow(beta1, tt);
+    const double bc2 = bc ? bc[1] : 1.0 - pow(beta2, tt);
     const double t = block_sum<NW>(q, sc);
     if (threadIdx.x == 0) {
         const float norm = (float)sqrt(t);

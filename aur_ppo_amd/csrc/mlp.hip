@@ -237,10 +237,13 @@ template <int HALVES>   // 16 slab rows per thread and half: 256 slabs (K7, K7w)
 __global__ __launch_bounds__(1024) void k_mlp_reduce(const float* __restrict__ slabs, const double* __restrict__ loss_part,
                                                      int n_slabs, int n_params, PpoHyper h, float* __restrict__ grads,
                                                      float* __restrict__ out_scalars, double* __restrict__ sq_part,
-                                                     float* __restrict__ step_dev, unsigned* __restrict__ tile_counter) {
+                                                     float* __restrict__ step_dev, unsigned* __restrict__ tile_counter,
+                                                     double beta1, double beta2, double* __restrict__ bc_out) {
     __shared__ float s_part[kRedGroups][64];
     const int pi = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int p = blockIdx.x * 64 + pi;
+    const bool stepper = step_dev && threadIdx.x == 0 && blockIdx.x == 0;
+    const float t_new = stepper ? *step_dev + 1.0f : 0.0f;      // the Adam step this minibatch is
     float acc = 0.0f;
     if (p < n_params) {
         // n_slabs <= kMaxGrid = 16 groups x 16: a thread's rows are all fetched before the first add (one memory round
@@ -251,6 +254,11 @@ __global__ __launch_bounds__(1024) void k_mlp_reduce(const float* __restrict__ s
         for (int j = 0; j < 16 * HALVES; ++j) {
             const int b = grp + j * kRedGroups;
             x[j] = b < n_slabs ? slabs[(size_t)b * n_params + p] : 0.0f;
+        }
+        if (stepper && bc_out) {
+            // Adam's bias corrections for the optimizer launch that follows, while the slab rows are on their way
+            bc_out[0] = 1.0 - pow(beta1, (double)t_new);
+            bc_out[1] = 1.0 - pow(beta2, (double)t_new);
         }
 #pragma unroll
         for (int h = 0; h < HALVES; ++h) {
@@ -274,8 +282,8 @@ __global__ __launch_bounds__(1024) void k_mlp_reduce(const float* __restrict__ s
             const double q = wave_sum((double)t * (double)t);
             if (pi == 0) sq_part[blockIdx.x] = q;
         }
-        if (step_dev && pi == 0 && blockIdx.x == 0) {
-            *step_dev += 1.0f;   // the Adam kernel (a later launch) reads the new step count
+        if (stepper) {
+            *step_dev = t_new;   // the Adam kernel (a later launch) reads the new step count
             tile_counter[0] = 0u;
             tile_counter[1] = 0u;
         }
@@ -383,7 +391,7 @@ __global__ __launch_bounds__(kThreads) void k_adam_chain(float* __restrict__ p, 
                                                          double eps, float* __restrict__ out_norm, float gscale, int nb_upd,
                                                          OperandCopies oc, const float4* __restrict__ rec, int rec_stride,
                                                          const int32_t* __restrict__ next_idx, int next_M,
-                                                         double (*__restrict__ stats)[2]) {
+                                                         double (*__restrict__ stats)[2], const double* __restrict__ bc) {
     __shared__ double sc[2][kThreads / kWave];
     __shared__ float s_coef;
     if ((int)blockIdx.x < nb_upd) {
@@ -432,7 +440,7 @@ __global__ __launch_bounds__(kThreads) void k_adam_chain(float* __restrict__ p, 
             __syncthreads();
         }
         AdamScalars a = adam_scalars<kThreads / kWave>(part ? part : &s_own, part ? n_part : 1, max_norm, lr_dev, step, beta1,
-                                                       beta2, eps, out_norm, blockIdx.x == 0, sc[0], &s_coef);
+                                                       beta2, eps, out_norm, blockIdx.x == 0, sc[0], &s_coef, bc);
         a.gscale = gscale;
         int k = 0;
         for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += nb_upd * kThreads, ++k) {
@@ -604,9 +612,11 @@ static int mlp_step_impl(const float* obs, const float* actions, const float* re
     }
     if (ev_end) AURPPO_HIP_TRY(hipEventRecord((hipEvent_t)ev_end, s));
     const int n_red = (n_params + 63) / 64;
+    // (words 8..11 of the counter block: Adam's two bias corrections, formed by the reduce for the optimizer launch behind it)
+    double* const bc = (chain && !chain->grad_only) ? reinterpret_cast<double*>(a.tile_counter + 8) : nullptr;
     hipLaunchKernelGGL(k_mlp_reduce<1>, dim3(n_red), dim3(1024), 0, s, a.slabs, a.loss_part, grid, n_params, a.h, grads,
                        out_scalars, (chain && !chain->grad_only) ? sq_part : nullptr, chain ? chain->step_dev : nullptr,
-                       a.tile_counter);
+                       a.tile_counter, bc ? chain->beta1 : 0.0, bc ? chain->beta2 : 0.0, bc);
     AURPPO_LAUNCH_CHECK("k_mlp_reduce");
     if (chain && !chain->grad_only) {
         int nb_upd = (n_params + kThreads * 4 - 1) / (kThreads * 4);
@@ -618,7 +628,7 @@ static int mlp_step_impl(const float* obs, const float* actions, const float* re
         hipLaunchKernelGGL(k_adam_chain, dim3(nb_upd + nsb), dim3(kThreads), 0, s, chain->params_rw, grads, chain->exp_avg,
                            chain->exp_avg_sq, n_params, sq_part, n_red, (float)chain->max_norm, chain->lr_dev,
                            chain->step_dev, chain->beta1, chain->beta2, chain->eps, chain->out_norm, 1.0f, nb_upd, oc,
-                           a.rec, a.rec_stride, chain->next_idx, chain->next_M, reinterpret_cast<double (*)[2]>(stats));
+                           a.rec, a.rec_stride, chain->next_idx, chain->next_M, reinterpret_cast<double (*)[2]>(stats), bc);
         AURPPO_LAUNCH_CHECK("k_adam_chain");
     }
     return AURPPO_OK;
@@ -634,16 +644,16 @@ OperandCopies no_operand_copies(int n_params) {   // every offset past the bucke
 
 int aurppo_mlp::launch_mlp_reduce(const float* slabs, const double* loss_part, int n_slabs, int n_params, const PpoHyper& h,
                                   float* grads, float* out_scalars, hipStream_t s, double* sq_part, float* step_dev,
-                                  unsigned* unused_counter) {
+                                  unsigned* unused_counter, double beta1, double beta2, double* bc_out) {
     // (k_mlp_reduce clears K7's tile counter when it advances the step: the caller names a word it may clear instead)
     AURPPO_REQUIRE(!step_dev || unused_counter, AURPPO_EINVAL, "launch_mlp_reduce: step_dev without a scratch counter");
     AURPPO_REQUIRE(n_slabs >= 1 && n_slabs <= 2 * kMaxGrid, AURPPO_ESHAPE, "launch_mlp_reduce: n_slabs=%d", n_slabs);
     if (n_slabs <= kMaxGrid)
         hipLaunchKernelGGL(k_mlp_reduce<1>, dim3((n_params + 63) / 64), dim3(1024), 0, s, slabs, loss_part, n_slabs, n_params, h,
-                           grads, out_scalars, sq_part, step_dev, unused_counter);
+                           grads, out_scalars, sq_part, step_dev, unused_counter, beta1, beta2, bc_out);
     else
         hipLaunchKernelGGL(k_mlp_reduce<2>, dim3((n_params + 63) / 64), dim3(1024), 0, s, slabs, loss_part, n_slabs, n_params, h,
-                           grads, out_scalars, sq_part, step_dev, unused_counter);
+                           grads, out_scalars, sq_part, step_dev, unused_counter, beta1, beta2, bc_out);
     AURPPO_LAUNCH_CHECK("k_mlp_reduce");
     return AURPPO_OK;
 }
@@ -651,7 +661,8 @@ int aurppo_mlp::launch_mlp_reduce(const float* slabs, const double* loss_part, i
 int aurppo_mlp::launch_adam_tail(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int n_params,
                                  const double* sq_part, double max_norm, const float* lr_dev, const float* step_dev,
                                  double beta1, double beta2, double eps, float* out_norm, hipStream_t s, const WideCopies* wide,
-                                 const float4* rec, int rec_stride, const int32_t* next_idx, int next_M, double* stats) {
+                                 const float4* rec, int rec_stride, const int32_t* next_idx, int next_M, double* stats,
+                                 const double* bc) {
     int nb_upd = (n_params + kThreads * 4 - 1) / (kThreads * 4);
     if (nb_upd > 64) nb_upd = 64;
     // no K7 operand copies (offsets past the bucket); K7w's if the caller names them; statistics of a next minibatch if it names one
@@ -660,7 +671,7 @@ int aurppo_mlp::launch_adam_tail(float* params, float* grads, float* exp_avg, fl
     const int nsb = (next_idx && stats) ? stat_blocks_for(next_M) : 0;
     hipLaunchKernelGGL(k_adam_chain, dim3(nb_upd + nsb), dim3(kThreads), 0, s, params, grads, exp_avg, exp_avg_sq, n_params, sq_part,
                        (n_params + 63) / 64, (float)max_norm, lr_dev, step_dev, beta1, beta2, eps, out_norm, 1.0f, nb_upd, oc, rec,
-                       rec_stride, nsb ? next_idx : (const int32_t*)nullptr, nsb ? next_M : 0, reinterpret_cast<double (*)[2]>(stats));
+                       rec_stride, nsb ? next_idx : (const int32_t*)nullptr, nsb ? next_M : 0, reinterpret_cast<double (*)[2]>(stats), bc);
     AURPPO_LAUNCH_CHECK("k_adam_chain");
     return AURPPO_OK;
 }
@@ -744,7 +755,7 @@ extern "C" int aurppo_mlp_ppo_apply_f32(float* params, float* grads, float* exp_
                        exp_avg_sq, n_params, (const double*)nullptr, 0, (float)max_norm, lr_dev, step_dev, beta1, beta2, eps,
                        out_norm, (float)grad_scale, nb_upd, oc_apply,
                        reinterpret_cast<const float4*>(rec), rec_floats == 16 ? 4 : 1, next_idx, next_idx ? next_M : 0,
-                       reinterpret_cast<double (*)[2]>(stats));
+                       reinterpret_cast<double (*)[2]>(stats), (const double*)nullptr);
     AURPPO_LAUNCH_CHECK("k_adam_chain");
     return AURPPO_OK;
 }

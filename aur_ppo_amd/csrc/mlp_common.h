@@ -183,7 +183,8 @@ int launch_mlp_step4(const MlpArgs& a, int grid, hipStream_t s);
 // Adam step count -- what launch_adam_tail (k_adam_chain without K7's extras: clip + Adam in one launch) then consumes.
 int launch_mlp_reduce(const float* slabs, const double* loss_part, int n_slabs, int n_params, const PpoHyper& h, float* grads,
                       float* out_scalars, hipStream_t s, double* sq_part = nullptr, float* step_dev = nullptr,
-                      unsigned* scratch_counter = nullptr);   // (with step_dev: a device word the kernel may clear)
+                      unsigned* scratch_counter = nullptr,    // (with step_dev: a device word the kernel may clear)
+                      double beta1 = 0.0, double beta2 = 0.0, double* bc_out = nullptr);   // bc_out: {1 - beta1^t, 1 - beta2^t} for launch_adam_tail
 // One thread's share of a minibatch's advantage partial sums: elements first, first + step, ... in that order (the sums are the
 // same bits as the plain loop's), four index loads and then four record loads in flight at a time -- the plain loop paid two
 // dependent memory round trips per element.
@@ -217,6 +218,6 @@ struct WideCopies {
 int launch_adam_tail(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int n_params, const double* sq_part,
                      double max_norm, const float* lr_dev, const float* step_dev, double beta1, double beta2, double eps,
                      float* out_norm, hipStream_t s, const WideCopies* wide = nullptr, const float4* rec = nullptr, int rec_stride = 1,
-                     const int32_t* next_idx = nullptr, int next_M = 0, double* stats = nullptr);
+                     const int32_t* next_idx = nullptr, int next_M = 0, double* stats = nullptr, const double* bc = nullptr);
 
 }  // namespace aurppo_mlp

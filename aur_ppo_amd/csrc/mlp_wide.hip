@@ -842,8 +842,9 @@ static int wide_step_impl(const float* obs, const float* actions, const float* r
     if (ev_end) AURPPO_HIP_TRY(hipEventRecord((hipEvent_t)ev_end, s));
     if (!tail) return launch_mlp_reduce(wv.slabs, wv.loss_part, pairs, n_params, a.h, grads, out_scalars, s);
     // (the reduce clears the tile counters for the launch that follows: the next chained call has no prepare pass to do it)
+    double* const bc = reinterpret_cast<double*>(wv.tile_counter + 8);     // Adam's bias corrections, reduce -> optimizer launch
     rc = launch_mlp_reduce(wv.slabs, wv.loss_part, pairs, n_params, a.h, grads, out_scalars, s, wv.sq_part, tail->step_dev,
-                           wv.tile_counter);
+                           wv.tile_counter, tail->beta1, tail->beta2, bc);
     if (rc != AURPPO_OK) return rc;
     WideCopies wc;
     for (int n = 0; n < 2; ++n)
@@ -851,7 +852,7 @@ static int wide_step_impl(const float* obs, const float* actions, const float* r
     wc.NL = num_layers; wc.Hd = hidden; wc.D = D; wc.wop = wv.wop;
     return launch_adam_tail(tail->params_rw, grads, tail->exp_avg, tail->exp_avg_sq, n_params, wv.sq_part, tail->max_norm,
                             tail->lr_dev, tail->step_dev, tail->beta1, tail->beta2, tail->eps, tail->out_norm, s,
-                            tail->next_idx ? &wc : nullptr, a.rec, a.rec_stride, tail->next_idx, tail->next_M, wv.stats);
+                            tail->next_idx ? &wc : nullptr, a.rec, a.rec_stride, tail->next_idx, tail->next_M, wv.stats, bc);
 }
 
 extern "C" int aurppo_mlp_wide_ppo_step_f32(const float* obs, const float* actions, const float* rec, const int32_t* idx, int M,
