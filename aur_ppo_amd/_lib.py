@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(_HERE, "libaurppo_hip.so")
 
 # every symbol include/aurppo.h declares (tests/test_abi.py checks the header against this list)
 SYMBOLS = (
-    "aurppo_version", "aurppo_last_error", "aurppo_device_count", "aurppo_k7_variant", "aurppo_gae_f32", "aurppo_gae_pack_f32",
+    "aurppo_version", "aurppo_last_error", "aurppo_device_count", "aurppo_k7_variant", "aurppo_reload_knobs", "aurppo_gae_f32", "aurppo_gae_pack_f32",
     "aurppo_mt19937_create", "aurppo_mt19937_destroy", "aurppo_mt19937_seed", "aurppo_mt19937_get_state",
     "aurppo_mt19937_set_state", "aurppo_mt19937_status_f32", "aurppo_arange_i32", "aurppo_shuffle_i32", "aurppo_shuffle_epochs_i32",
     "aurppo_gather_f32", "aurppo_loss_workspace_bytes", "aurppo_loss_fwd_bwd_f32", "aurppo_loss_fwd_bwd_packed_f32",

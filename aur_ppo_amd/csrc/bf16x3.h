@@ -269,104 +269,4 @@ __device__ __host__ __forceinline__ int wop3_places(int net, int is_w2, int row,
     return 2;
 }
 
-// =====================================================================================================================
-// k_mlp_step4 (mlp4.hip): the TRANSPOSED arrangement.  A wave carries a whole net for its 32 samples: Z^T[o][s] = W . X^T, so
-// the sample is on the LANE of every accumulator and the feature index runs over its registers -- and a 32x32 accumulator
-// block, converted to bf16 planes in place, IS the B operand of the next layer's product (it sums over the block's ROW
-// index): no LDS round trip, no barrier between layers.  The hardware's k slot (lane half h, element j) of k-step ks then
-// holds feature
-//     kappa(ks, h, j) = 16 ks + 8 (j >> 2) + 4 h + (j & 3)
-// so the weights (the A operands, streamed from L2 in operand order) are laid out in THAT k order.
-__device__ __host__ __forceinline__ int kappa(int ks, int h, int j) { return 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3); }
-// inverse: feature c -> (ks, h, j)
-__device__ __host__ __forceinline__ void kappa_inv(int c, int& ks, int& h, int& j) {
-    ks = c >> 4;
-    const int t = c & 15;
-    h = (t >> 2) & 1;
-    j = 4 * (t >> 3) + (t & 3);
-}
-
-// operand-order weight copies of one net: 30 blocks of 64 lanes x 8 bf16 per plane
-//   id  0.. 7  W1  as A, natural k:   block (ob, ks): lane (r, h), j -> W1[32 ob + r][16 ks + 8 h + j]        (0 beyond D)
-//   id  8..15  W2  as A, kappa order: block (ob, ks):               -> W2[32 ob + r][kappa(ks, h, j)]
-//   id 16..19  W3  as A, kappa order, 32 rows (16.. zero): (ks)      -> W3[r][kappa(ks, h, j)]
-//   id 20..21  W3^T as A (K = 16, one k-step): block (ib)            -> W3[kappa(0, h, j)][32 ib + r]
-//   id 22..29  W2^T as A, kappa order: block (ib, ks)                -> W2[kappa(ks, h, j)][32 ib + r]
-constexpr int kW4Blocks = 30;
-constexpr int kW4Elems = 2 * kW4Blocks * 3 * kWopBlock;       // both nets, bf16 elements
-__device__ __host__ __forceinline__ int wop4_index(int net, int id, int p, int lane, int j) {
-    return (((net * kW4Blocks + id) * 3 + p) * 64 + lane) * 8 + j;
-}
-enum { kW4_W1 = 0, kW4_W2 = 8, kW4_W3 = 16, kW4_W3T = 20, kW4_W2T = 22 };
-// where element (row, col) of layer `layer` (0: W1, 1: W2, 2: W3) of net `net` lands (plane 0; planes follow at + kWopBlock)
-__device__ __host__ __forceinline__ int wop4_places(int net, int layer, int row, int col, int (&idx)[2]) {
-    int ks, h, j;
-    if (layer == 0) {
-        idx[0] = wop4_index(net, kW4_W1 + (row >> 5) * 4 + (col >> 4), 0, (row & 31) + 32 * ((col >> 3) & 1), col & 7);
-        return 1;
-    }
-    if (layer == 1) {
-        kappa_inv(col, ks, h, j);
-        idx[0] = wop4_index(net, kW4_W2 + (row >> 5) * 4 + ks, 0, (row & 31) + 32 * h, j);
-        kappa_inv(row, ks, h, j);
-        idx[1] = wop4_index(net, kW4_W2T + (col >> 5) * 4 + ks, 0, (col & 31) + 32 * h, j);
-        return 2;
-    }
-    kappa_inv(col, ks, h, j);
-    idx[0] = wop4_index(net, kW4_W3 + ks, 0, row + 32 * h, j);                 // row < 16
-    kappa_inv(row, ks, h, j);                                                   // ks == 0
-    idx[1] = wop4_index(net, kW4_W3T + (col >> 5), 0, (col & 31) + 32 * h, j);
-    return 2;
-}
-
-typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ bf16x8 as_frag(unsigned a, unsigned b, unsigned c, unsigned d) {
-    const u32x4v v = {a, b, c, d};
-    return __builtin_bit_cast(bf16x8, v);
-}
-// 8 consecutive registers of an accumulator block (one k-step of the next product) -> the three planes of a B fragment
-__device__ __forceinline__ Frag3 regs_to_frag(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7) {
-    unsigned a[3], b[3], c[3], d[3];
-    split3(v0, v1, a[0], a[1], a[2]);
-    split3(v2, v3, b[0], b[1], b[2]);
-    split3(v4, v5, c[0], c[1], c[2]);
-    split3(v6, v7, d[0], d[1], d[2]);
-    Frag3 f;
-#pragma unroll
-    for (int p = 0; p < 3; ++p) f.p[p] = as_frag(a[p], b[p], c[p], d[p]);
-    return f;
-}
-// the two fragments (k-steps 2b, 2b+1) of accumulator block b as they stand, stored into a [sample][feature] X-layout image:
-// lane = sample s, features 32 b + 8 gq + 4 h + {0..3} per 8-byte store
-__device__ __forceinline__ void store_frags_x(char* img, int s, int h, int b, const Frag3& f0, const Frag3& f1) {
-#pragma unroll
-    for (int gq = 0; gq < 4; ++gq) {
-        const int o = xoff(s, 32 * b + 8 * gq + 4 * h);
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            const u32x4v q = __builtin_bit_cast(u32x4v, gq < 2 ? f0.p[p] : f1.p[p]);
-            *reinterpret_cast<u32x2*>(img + p * kXPlane + o) = (gq & 1) ? u32x2{q.z, q.w} : u32x2{q.x, q.y};
-        }
-    }
-}
-// 16x16x32 operands from a [k = sample][column] image by transposed reads (all 32 samples = one k-step):
-// A[m = c0 + 0..15][k = s] or B[k = s][n = c0 + 0..15];  X-layout image (128-B rows, swizzled)
-__device__ __forceinline__ Frag3 x_cols16(const char* img, int c0, int lane) {
-    const TrLane t = tr_lane16(lane);
-    const int o0 = xoff(t.kq, c0 + t.m0), o1 = xoff(t.kq + 4, c0 + t.m0);
-    Frag3 f;
-#pragma unroll
-    for (int p = 0; p < 3; ++p) f.p[p] = join_tr(lds_tr(img + p * kXPlane + o0), lds_tr(img + p * kXPlane + o1));
-    return f;
-}
-// the same from a small unswizzled image
-__device__ __forceinline__ Frag3 plain_cols16(const char* img, int rowb, int planeb, int c0, int lane) {
-    const TrLane t = tr_lane16(lane);
-    const int o0 = t.kq * rowb + 2 * (c0 + t.m0), o1 = o0 + 4 * rowb;
-    Frag3 f;
-#pragma unroll
-    for (int p = 0; p < 3; ++p) f.p[p] = join_tr(lds_tr(img + p * planeb + o0), lds_tr(img + p * planeb + o1));
-    return f;
-}
-
 }  // namespace bf3

@@ -48,7 +48,7 @@ static inline int aurppo_device_slot() {
 // once per process -- or on every call when AURPPO_TEST_KNOBS=1 (tests/conftest.py), so that one test process can flip
 // them.  None of them changes results beyond summation order; the defaults are the product configuration.
 struct AurppoKnobs {
-    int k7_variant;        // AURPPO_K7_VARIANT: 2 = f32 MFMA k_mlp_step2, 3 = 3 x bf16-split MFMA k_mlp_step3 (mlp3.hip); default: see api.hip
+    int k7_variant;        // AURPPO_K7_VARIANT: 3 (default) = 3 x bf16-split MFMA k_mlp_step3 (mlp3.hip), 2 = f32 MFMA k_mlp_step2; always one of the two (api.hip normalises)
     int k7_spare_cus;      // AURPPO_MLP_SPARE_CUS: CUs K7 / K7w leave to the side stream's shuffle kernels (default 8)
     int static_tiles;      // AURPPO_STATIC_TILES=1: K7 / K7w deal tiles by static stride instead of through the counter, which
                            // fixes the order of every sum (bit-reproducible gradients; tests/test_determinism.py)
@@ -58,7 +58,7 @@ struct AurppoKnobs {
     int k2_post_stream;    // AURPPO_K2_POST_STREAM: 1 (default since round 3) = link + resolve on a third stream of the handle; 0 = behind accept / fill
     int k2_starve;         // AURPPO_TEST_K2_STARVE (tests): the twist keeps this per cent of one shuffle's draws in stock, so shuffles run dry
     int k2_accept3_wgs;    // AURPPO_K2_ACCEPT3_WGS: workgroups of k_fy_accept3's relay (default 6)
-    int k2_accept;         // AURPPO_K2_ACCEPT: 1 = k_fy_accept (workgroup rounds, default), 2 = k_fy_accept2 (wave relay; bit-exact, measured slower), 3 = k_fy_accept3 (workgroup relay)
+    int k2_accept;         // AURPPO_K2_ACCEPT: 3 (default) = k_fy_accept3 (relay between workgroups), 1 = k_fy_accept (one workgroup, rounds); always one of the two
     int gather_unroll;     // AURPPO_GATHER_UNROLL (0 = by row width)
     int gather_rows;       // AURPPO_GATHER_ROWS (0 = by row width)
 };

@@ -314,13 +314,12 @@ __global__ __launch_bounds__(1024) void k_mlp_reduce(const float* __restrict__ s
 }
 
 // Where an updated weight is also kept in MFMA-operand order for the next K7 launch (W1 in k_mlp_step2's fp32 B-operand order;
-// W1 / W2 (/ W3) as bf16 planes for k_mlp_step3 / 4).  Offsets past the bucket switch a copy off.
+// W1 / W2 as bf16 planes for k_mlp_step3).  Offsets past the bucket switch a copy off.
 struct OperandCopies {
     int w1_actor, w1_critic, D;
     float* w1op;
     int w2_actor, w2_critic;
     unsigned short* wop3;
-    int w3_actor, w3_critic, A, wop_mode;
     aurppo_mlp::WideCopies wide;     // K7w's copies (wide.wop == nullptr: none)
 };
 __device__ __forceinline__ void refresh_operand_copies(const OperandCopies& oc, int i, float pn) {
@@ -346,7 +345,7 @@ __device__ __forceinline__ void refresh_operand_copies(const OperandCopies& oc, 
             }
         return;
     }
-    const int D = oc.D, A = oc.A;
+    const int D = oc.D;
     const int ea = i - oc.w1_actor, ec = i - oc.w1_critic;
     const int e = (ea >= 0 && ea < H * D) ? ea : ((ec >= 0 && ec < H * D) ? ec : -1);
     if (e >= 0 && oc.w1op) {
@@ -354,21 +353,16 @@ __device__ __forceinline__ void refresh_operand_copies(const OperandCopies& oc, 
         const int row = e / D, k = e - row * D;
         oc.w1op[((net * 2 + (row >> 5)) * 32 + (k >> 1)) * kWave + (row & 31) + 32 * (k & 1)] = pn;
     }
-    if (oc.wop3) {      // k_mlp_step3 / 4's copies: the bf16 planes of the new value wherever the weight appears as an operand
+    if (oc.wop3) {      // k_mlp_step3's copies: the bf16 planes of the new value wherever the weight appears as an operand
         const int e2a = i - oc.w2_actor, e2c = i - oc.w2_critic;
         const int e2 = (e2a >= 0 && e2a < H * H) ? e2a : ((e2c >= 0 && e2c < H * H) ? e2c : -1);
-        const int e3a = i - oc.w3_actor, e3c = i - oc.w3_critic;
-        const int e3 = oc.wop_mode != 4 ? -1 : ((e3a >= 0 && e3a < A * H) ? e3a : ((e3c >= 0 && e3c < H) ? e3c : -1));
-        if (e >= 0 || e2 >= 0 || e3 >= 0) {
-            const int layer = e >= 0 ? 0 : (e2 >= 0 ? 1 : 2);
-            const bool is_w2 = layer == 1;
-            const int net = layer == 0 ? ((ea >= 0 && ea < H * D) ? 0 : 1)
-                                       : (layer == 1 ? ((e2a >= 0 && e2a < H * H) ? 0 : 1) : ((e3a >= 0 && e3a < A * H) ? 0 : 1));
-            const int row = layer == 0 ? e / D : (layer == 1 ? e2 / H : e3 / H);
-            const int col = layer == 0 ? e - (e / D) * D : (layer == 1 ? e2 % H : e3 % H);
+        if (e >= 0 || e2 >= 0) {
+            const bool is_w2 = e < 0;
+            const int net = is_w2 ? ((e2a >= 0 && e2a < H * H) ? 0 : 1) : ((ea >= 0 && ea < H * D) ? 0 : 1);
+            const int row = is_w2 ? e2 / H : e / D;
+            const int col = is_w2 ? e2 % H : e - (e / D) * D;
             int at[2];
-            const int n_at = oc.wop_mode == 4 ? bf3::wop4_places(net, layer, row, col, at)
-                                              : bf3::wop3_places(net, is_w2 ? 1 : 0, row, col, at);
+            const int n_at = bf3::wop3_places(net, is_w2 ? 1 : 0, row, col, at);
             unsigned p0, p1, p2;
             bf3::split3(pn, 0.0f, p0, p1, p2);
             for (int q = 0; q < n_at; ++q) {
@@ -476,7 +470,7 @@ extern "C" size_t aurppo_mlp_workspace_bytes(int n_params) {
     return sizeof(double) * 2 * kStatBlocks + sizeof(double) * 8 * kMaxGrid + sizeof(float) * (size_t)kMaxGrid * (size_t)n_params + 64 +
            sizeof(unsigned long long) * 44 * kMaxGrid + sizeof(float) * 4 * 32 * 64 + 64 +
            ((sizeof(double) * (size_t)((n_params + 63) / 64) + 63) / 64) * 64 + 64 +
-           (mlp_step3_wop_bytes() > mlp_step4_wop_bytes() ? mlp_step3_wop_bytes() : mlp_step4_wop_bytes()) + 64;
+           mlp_step3_wop_bytes() + 64;
 }
 
 namespace {
@@ -567,8 +561,8 @@ static int mlp_step_impl(const float* obs, const float* actions, const float* re
     const int sb = stat_blocks_for(M);
     a.n_stat_blocks = sb;
     const AurppoKnobs& knobs = aurppo_knobs();
-    // 2: k_mlp_step2 (f32 MFMA); 3: k_mlp_step3 (3 x bf16-split MFMA, two tile sets); 4: k_mlp_step4 (the same arithmetic, transposed)
-    const int variant = (knobs.k7_variant == 3 || knobs.k7_variant == 4) ? knobs.k7_variant : 2;
+    // 2: k_mlp_step2 (f32 MFMA); 3: k_mlp_step3 (3 x bf16-split MFMA); normalised in api.hip::parse_knobs
+    const int variant = knobs.k7_variant;
     a.w1op = wv.w1op;
     a.tile_counter = wv.tile_counter;
     a.static_tiles = knobs.static_tiles ? 1 : 0;
@@ -578,8 +572,8 @@ static int mlp_step_impl(const float* obs, const float* actions, const float* re
         hipLaunchKernelGGL(k_adv_stats_idx, dim3(sb), dim3(kThreads), 0, s, a.rec, a.rec_stride, idx, M,
                            reinterpret_cast<double (*)[2]>(stats), params, a.L.w1[0], a.L.w1[1], D, a.w1op, a.tile_counter);
         AURPPO_LAUNCH_CHECK("k_adv_stats_idx");
-        if (variant >= 3) {
-            const int rc = variant == 3 ? launch_mlp3_prep(params, a.L, D, wv.wop3, s) : launch_mlp4_prep(params, a.L, D, A, wv.wop3, s);
+        if (variant == 3) {
+            const int rc = launch_mlp3_prep(params, a.L, D, wv.wop3, s);
             if (rc != AURPPO_OK) return rc;
         }
     }
@@ -604,10 +598,10 @@ static int mlp_step_impl(const float* obs, const float* actions, const float* re
     // config 4's shard, 512 envs x 128 steps / 4 = 512 tiles against 2 x 248 -- gets all the CUs: the stragglers' second round
     // was a quarter of that launch (stamps at M = 16 384: tile loop 12.0 us median, 22.2 us for the sets that drew a second tile)
     if (n_tiles > 2 * grid && n_tiles <= 2 * cus && cus <= kMaxGrid) grid = cus;
-    if (grid > (n_tiles + 1) / 2) grid = (n_tiles + 1) / 2;     // two tile sets (variant 4: two waves of each net) per workgroup
+    if (grid > (n_tiles + 1) / 2) grid = (n_tiles + 1) / 2;     // two tile sets per workgroup
     if (ev_begin) AURPPO_HIP_TRY(hipEventRecord((hipEvent_t)ev_begin, s));
     {
-        const int rc = variant == 4 ? launch_mlp_step4(a, grid, s) : (variant == 3 ? launch_mlp_step3(a, grid, s) : launch_mlp_step2(a, grid, s));
+        const int rc = variant == 3 ? launch_mlp_step3(a, grid, s) : launch_mlp_step2(a, grid, s);
         if (rc != AURPPO_OK) return rc;
     }
     if (ev_end) AURPPO_HIP_TRY(hipEventRecord((hipEvent_t)ev_end, s));
@@ -623,7 +617,7 @@ static int mlp_step_impl(const float* obs, const float* actions, const float* re
         if (nb_upd > 64) nb_upd = 64;
         const int nsb = chain->next_idx ? stat_blocks_for(chain->next_M) : 0;
         OperandCopies oc = {a.L.w1[0], a.L.w1[1], D, a.w1op, a.L.w2[0], a.L.w2[1],
-                            variant >= 3 ? wv.wop3 : (unsigned short*)nullptr, a.L.w3[0], a.L.w3[1], A, variant, {}};
+                            variant == 3 ? wv.wop3 : (unsigned short*)nullptr, {}};
         oc.wide.wop = nullptr;
         hipLaunchKernelGGL(k_adam_chain, dim3(nb_upd + nsb), dim3(kThreads), 0, s, chain->params_rw, grads, chain->exp_avg,
                            chain->exp_avg_sq, n_params, sq_part, n_red, (float)chain->max_norm, chain->lr_dev,
@@ -636,7 +630,7 @@ static int mlp_step_impl(const float* obs, const float* actions, const float* re
 
 namespace {
 OperandCopies no_operand_copies(int n_params) {   // every offset past the bucket: no copy is refreshed
-    OperandCopies oc = {n_params, n_params, 1, nullptr, n_params, n_params, nullptr, n_params, n_params, 1, 2, {}};
+    OperandCopies oc = {n_params, n_params, 1, nullptr, n_params, n_params, nullptr, {}};
     oc.wide.wop = nullptr;
     return oc;
 }
@@ -741,15 +735,11 @@ extern "C" int aurppo_mlp_ppo_apply_f32(float* params, float* grads, float* exp_
     const WsView wv = ws_view(workspace, n_params);
     double* stats = wv.stats;
     float* w1op = wv.w1op;
-    // the actor head's width from the layout: its bias follows its weight in the bucket (torch's parameter order)
-    int A_apply = (layout_h[5] - layout_h[4]) / H;
-    if (A_apply < 1 || A_apply > AP) A_apply = AP;
     int nb_upd = (n_params + kThreads * 4 - 1) / (kThreads * 4);
     if (nb_upd > 64) nb_upd = 64;
     const int nsb = next_idx ? stat_blocks_for(next_M) : 0;
     OperandCopies oc_apply = {layout_h[0], layout_h[6], D, w1op, layout_h[2], layout_h[8],
-                              aurppo_knobs().k7_variant >= 3 ? wv.wop3 : (unsigned short*)nullptr, layout_h[4], layout_h[10],
-                              A_apply, aurppo_knobs().k7_variant, {}};
+                              aurppo_knobs().k7_variant == 3 ? wv.wop3 : (unsigned short*)nullptr, {}};
     oc_apply.wide.wop = nullptr;
     hipLaunchKernelGGL(k_adam_chain, dim3(nb_upd + nsb), dim3(kThreads), 0, (hipStream_t)stream, params, grads, exp_avg,
                        exp_avg_sq, n_params, (const double*)nullptr, 0, (float)max_norm, lr_dev, step_dev, beta1, beta2, eps,

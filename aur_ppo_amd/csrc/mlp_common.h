@@ -37,9 +37,9 @@ struct MlpArgs {
     float* slabs;          // (grid, n_params) per-workgroup gradient slabs
     double* loss_part;     // (grid, 8)
     unsigned long long* stamps;  // diagnostic build: (grid, 16) cycle counters
-    unsigned* tile_counter;  // next tile to hand out ([0]; k_mlp_step4: [0] actor, [1] critic), zeroed by k_adv_stats_idx / k_mlp_reduce
+    unsigned* tile_counter;  // next tile to hand out ([0]), zeroed by k_adv_stats_idx / k_mlp_reduce
     float* w1op;           // two-set kernel: W1 slices in MFMA B-operand order, [4 waves][32 k-steps][64 lanes]
-    const void* wop3;      // k_mlp_step3 / k_mlp_step4: bf16 planes of the weights in operand order (bf16x3.h)
+    const void* wop3;      // k_mlp_step3: bf16 planes of the weights in operand order (bf16x3.h)
     const double* stats;   // (kStatBlocks, 2) advantage partial sums
     int n_stat_blocks;
     int D, A;
@@ -173,11 +173,6 @@ size_t mlp_step3_lds_bytes();
 size_t mlp_step3_wop_bytes();
 int launch_mlp3_prep(const float* params, const MlpLayout& L, int D, void* wop3, hipStream_t s);
 int launch_mlp_step3(const MlpArgs& a, int grid, hipStream_t s);
-// mlp4.hip: the transposed arrangement (one wave = one net of a 32-sample tile, no barriers; AURPPO_K7_VARIANT=4)
-size_t mlp_step4_lds_bytes();
-size_t mlp_step4_wop_bytes();
-int launch_mlp4_prep(const float* params, const MlpLayout& L, int D, int A, void* wop4, hipStream_t s);
-int launch_mlp_step4(const MlpArgs& a, int grid, hipStream_t s);
 // mlp.hip: k_mlp_reduce alone (grads[p] = fixed-order sum over n_slabs slabs, loss scalars folded) -- mlp_wide.hip's tail.
 // sq_part / step_dev != nullptr: also leave the clip's partial sums of squares (one per 64 parameters) and advance the
 // Adam step count -- what launch_adam_tail (k_adam_chain without K7's extras: clip + Adam in one launch) then consumes.

@@ -12,7 +12,7 @@
 //      output, a register), two phases share a barrier, and eight helper waves store the words -- UNTEMPERED: the consumers
 //      temper what they read -- to a ring in HBM one barrier behind the four that twist.  It runs one shuffle ahead of its
 //      consumer on the handle's own stream.
-//   1b. k_fy_accept3 (default; k_fy_accept / k_fy_accept2 are the one-workgroup builds it grew from) -- turns the draws into
+//   1b. k_fy_accept3 (default; k_fy_accept is the one-workgroup build it grew from, AURPPO_K2_ACCEPT=1) -- turns the draws into
 //      accept/reject decisions.  Whether draw p is accepted depends on the index i it is tried against, i.e. on how
 //      many earlier draws were accepted -- a triangular system.  A thread resolves its own consecutive draws exactly
 //      given its starting index; inside a workgroup the starting indices are the fixed point of
@@ -484,289 +484,8 @@ __global__ __launch_bounds__(kAccThreads) void k_fy_accept(const uint32_t* __res
     }
 }
 
-// k_fy_accept2 -- the same decisions with NO workgroup barrier on the chain.
-//
-// Stamps of k_fy_accept (tools/accept_stamps.py, round 3): a step of 8192 draws costs ~11 k cycles, of which 5.3 k are spent
-// INSIDE the 3.25 workgroup barriers of its fixed-point rounds (1024 threads: every round waits for the slowest of 16
-// waves) and 2.2 k publishing / re-reading wave sums around them.  What one chunk of draws needs from everything before it
-// is a single number -- the index i it starts at -- so the chain can be a relay between WAVES instead of a sequence of
-// workgroup-wide rounds:
-//   * wave w owns chunks w, w + W, w + 2W, ... of 64 x kWpt consecutive draws; everything inside a chunk (counts, prefix
-//     sums, the fixed point of the lanes' starting indices) is wave-local: DPP scans, ballots, no LDS, no barrier;
-//   * a wave evaluates its chunk AHEAD of time from a guessed starting index (the expected trajectory
-//     (i + 1) exp(-draws / (mask + 1)) - 1 from the last index it knows exactly), keeping per lane the slack within which
-//     its count cannot change (as k_fy_accept does);
-//   * then it waits for its predecessor's confirmation -- one 64-bit word {chunk, index after it} in LDS --, checks that
-//     every lane's true starting index lies inside its slack (else those lanes recount: a wave-local fixed point), and
-//     publishes its own confirmation BEFORE emitting its targets: the relay's critical path per chunk is
-//     "poll, one ballot, one LDS store".
-// Decisions and the words consumed are exactly numpy's (the same literal rule decides whenever a shortcut does not apply).
-template <int kWaves, int kWpt>
-__global__ __launch_bounds__(kWaves * 64) void k_fy_accept2(const uint32_t* __restrict__ ring, long long ring_cap,
-                                                            int32_t* __restrict__ j, int n, long long* __restrict__ posv,
-                                                            int done_slot) {
-    constexpr int kChunk = kWave * kWpt;
-    static_assert(kWpt % 4 == 0 && kWpt <= kRingMirror, "draws are fetched four at a time from a mirrored ring");
-    __shared__ unsigned long long s_conf[kWaves];     // slot c mod kWaves: {chunk c (high word), index after chunk c (low word, signed)}
-    const int tid = threadIdx.x, lane = tid & (kWave - 1);
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const long long cursor0 = posv[1];                // stream offset of the first unread draw
-    const long long avail = posv[0];                  // draws written so far (the fill for this shuffle has completed)
-    const long long rpos0 = cursor0 % ring_cap;
-    // (the chunk number is stored + kWaves, so that the largest word is the latest chunk)
-    auto pack = [](int c, int i) -> unsigned long long { return ((unsigned long long)(unsigned)(c + kWaves) << 32) | (unsigned long long)(unsigned)i; };
-    auto chunk_of = [](unsigned long long e) -> int { return (int)(e >> 32) - kWaves; };
-    if (tid < kWaves) s_conf[tid] = pack(tid - kWaves, n - 1);      // slot kWaves-1 = "chunk -1": the shuffle starts at index n - 1
-    __syncthreads();
-    typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));
-    uint32_t ynext[kWpt];
-    // ring slot of my first draw of the chunk being fetched, advanced by kWaves chunks per fetch (no 64-bit division per chunk)
-    long long r_next = (rpos0 + (long long)wave * kChunk + (long long)lane * kWpt) % ring_cap;
-    const long long r_step = ((long long)kWaves * kChunk) % ring_cap;
-    auto fetch = [&](int c) {        // branch-free: draws past `avail` come from some valid slot and are never looked at
-        const long long r0 = r_next;
-        r_next += r_step;
-        if (r_next >= ring_cap) r_next -= ring_cap;
-        const u32x4u* src = reinterpret_cast<const u32x4u*>(ring + r0);
-#pragma unroll
-        for (int q = 0; q < kWpt / 4; ++q) {
-            const u32x4u v = src[q];
-            ynext[4 * q + 0] = v.x; ynext[4 * q + 1] = v.y; ynext[4 * q + 2] = v.z; ynext[4 * q + 3] = v.w;
-        }
-    };
-    fetch(wave);
-    int c_ref = -1, i_ref = n - 1;                    // the reference of a chunk's guess: the latest confirmed chunk and the index after it
-#ifdef AURPPO_ACC_STAMPS
-    unsigned long long d_absdelta = 0, d_window = 0, d_notfast = 0, d_empty = 0;
-    unsigned long long d_chunks = 0, d_recount = 0, d_polls = 0, d_cyc[6] = {0, 0, 0, 0, 0, 0}, d_last = __builtin_readcyclecounter(), d_ready = 0;
-#define DSTAMP(k) do { const unsigned long long t__ = __builtin_readcyclecounter(); d_cyc[k] += t__ - d_last; d_last = t__; } while (0)
-#else
-#define DSTAMP(k) do { } while (0)
-#endif
-    for (int c = wave;; c += kWaves) {
-        const long long cbase = cursor0 + (long long)c * kChunk;
-        uint32_t y[kWpt];
-        int nhave = 0;                                // my draws that exist (a prefix of the kWpt)
-#pragma unroll
-        for (int u = 0; u < kWpt; ++u) {
-            y[u] = mt_temper(ynext[u]);     // the ring holds the untempered words
-            nhave += (cbase + (long long)lane * kWpt + u) < avail ? 1 : 0;
-        }
-        fetch(c + kWaves);
-        DSTAMP(0);      // draws of this chunk in registers, next fetch issued
-        // the literal rule for my draws from starting index i0: #accepted; optionally emits targets / #consumed
-        auto walk = [&](int i0, bool emit, int& consumed) -> int {
-            int i = i0, acc = 0;
-            consumed = 0;
-#pragma unroll
-            for (int u = 0; u < kWpt; ++u) {
-                if (u < nhave && i >= 1) {
-                    const uint32_t v = y[u] & (0xffffffffu >> __clz(i));
-                    ++consumed;
-                    if (v <= (uint32_t)i) {
-                        if (emit) j[i] = (int32_t)v;
-                        --i;
-                        ++acc;
-                    }
-                }
-            }
-            return acc;
-        };
-        uint32_t dn = 0, up = 0;
-        bool sure = false;
-        int ref_i0 = 0;
-        bool wave_fast = false;
-        auto eval = [&](int i0) -> int {          // as in k_fy_accept: #draws <= i0 - kWpt, and the slack of that count
-            const bool shape = nhave == kWpt && i0 > kWpt && __clz(i0) == __clz(i0 - kWpt);
-            const uint32_t mask = 0xffffffffu >> __clz(i0 | 1);
-            const uint32_t lo = (uint32_t)(i0 - kWpt);
-            int cc = 0;
-            uint32_t d = 0xffffffffu, pp = 0xffffffffu;
-#pragma unroll
-            for (int u = 0; u < kWpt; ++u) {
-                const uint32_t v = y[u] & mask;
-                const bool le = v <= lo;
-                cc += le ? 1 : 0;
-                d = le ? min(d, lo - v) : d;
-                pp = le ? pp : min(pp, v - lo - 1u);
-            }
-            dn = d;
-            up = pp;
-            sure = shape && pp >= (uint32_t)kWpt;
-            ref_i0 = i0;
-            wave_fast = __builtin_amdgcn_ballot_w64(!sure) == 0ull;
-            if (!wave_fast) {
-                int consumed;
-                cc = walk(i0, false, consumed);
-            }
-            return cc;
-        };
-        auto still_ok = [&](int i0) -> bool {
-            const int delta = i0 - ref_i0;
-            const bool shape = i0 > kWpt && __clz(i0) == __clz(i0 - kWpt) && __clz(i0) == __clz(ref_i0);
-            const bool room = delta >= 0 ? up >= (uint32_t)(kWpt + delta) : dn >= (uint32_t)(-delta);
-            return delta == 0 || (sure && shape && room);
-        };
-        // ---- ahead of time: counts from the expected starting index
-        const int slot_prev = (c + kWaves - 1) % kWaves;
-        int i_start;
-#ifdef AURPPO_ACC_STAMPS
-        int i_guess = 0;
-#endif
-        bool have_start = false;
-        {
-            // the latest confirmation anybody has published: the closer the reference, the better the guess
-            unsigned long long e = __hip_atomic_load(&s_conf[lane & (kWaves - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#pragma unroll
-            for (int off = kWaves / 2; off > 0; off >>= 1) {
-                const unsigned lo_w = (unsigned)__shfl_xor((int)(unsigned)e, off, kWave), hi_w = (unsigned)__shfl_xor((int)(e >> 32), off, kWave);
-                const unsigned long long o = ((unsigned long long)hi_w << 32) | lo_w;
-                e = o > e ? o : e;
-            }
-            c_ref = __builtin_amdgcn_readfirstlane(chunk_of(e));
-            i_ref = __builtin_amdgcn_readfirstlane((int)(unsigned)e);
-            if (c_ref == c - 1) {             // already confirmed: no guess needed
-                i_start = i_ref;
-                have_start = true;
-            } else {
-                const float m1 = (float)(0xffffffffu >> __clz(i_ref | 1)) + 1.0f;
-                const float between = (float)((c - 1 - c_ref) * kChunk);
-                i_start = (int)((float)(i_ref + 1) * __expf(-between / m1)) - 1;
-#ifdef AURPPO_ACC_STAMPS
-                i_guess = i_start;
-#endif
-            }
-        }
-        int cnt, incl;
-        if (have_start && i_start < 1) {
-            // the shuffle ended before this chunk: pass the word on and leave
-            if (lane == 0) __hip_atomic_store(&s_conf[c % kWaves], pack(c, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            break;
-        }
-        {
-            const float m1 = (float)(0xffffffffu >> __clz(i_start | 1)) + 1.0f;
-            const int g0 = (int)((float)(i_start + 1) * (1.0f - __expf(-(float)(lane * kWpt) / m1)));   // expected accepts before my draws
-            cnt = eval(i_start - g0);
-            incl = wave_incl_scan(cnt);
-        }
-        // ... and, still ahead of time, the range of chunk starting indices for which every lane's count stands: lane l's
-        // own index cur_i0 = start - (accepts before it) must stay inside the slack of its count and inside its octave
-        int LO, HI, total_ahead;
-        {
-            int lo_l = ref_i0, hi_l = ref_i0;
-            if (sure) {
-                const int k = 31 - __clz(ref_i0);
-                const int dnc = dn > 0x3fffffffu ? 0x3fffffff : (int)dn, upc = up > 0x3fffffffu ? 0x3fffffff : (int)up;
-                lo_l = max(ref_i0 - dnc, (1 << k) + kWpt);
-                hi_l = min(ref_i0 + (upc - kWpt), (int)((2u << k) - 1u));
-            }
-            const int ex = incl - cnt;
-            int a = lo_l + ex, b = hi_l + ex;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                a = max(a, __shfl_xor(a, off, kWave));
-                b = min(b, __shfl_xor(b, off, kWave));
-            }
-            LO = __builtin_amdgcn_readfirstlane(a);
-            HI = __builtin_amdgcn_readfirstlane(b);
-            total_ahead = __builtin_amdgcn_readlane(incl, kWave - 1);
-        }
-        DSTAMP(1);      // evaluated ahead of time
-        // ---- the relay: my predecessor's confirmation.  From here to the store of my own confirmation is the critical path of
-        // the whole shuffle: highest priority on the SIMD (the wave sharing it is in its ahead-of-time or emit code), and in the
-        // usual case nothing but "is the start inside [LO, HI]".
-        __builtin_amdgcn_s_setprio(3);
-        if (!have_start) {
-            unsigned long long e;
-            while (chunk_of(e = __hip_atomic_load(&s_conf[slot_prev], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != c - 1) {
-#ifdef AURPPO_ACC_STAMPS
-                ++d_polls;
-#endif
-                __builtin_amdgcn_s_sleep(0);
-            }
-            i_start = (int)(unsigned)e;
-            if (i_start < 1) {
-                if (lane == 0) __hip_atomic_store(&s_conf[c % kWaves], pack(c, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                break;
-            }
-        }
-        DSTAMP(2);      // waited for the predecessor
-#ifdef AURPPO_ACC_STAMPS
-        if (!have_start) {
-            d_absdelta += (unsigned long long)abs(i_start - i_guess);
-            d_window += (unsigned long long)(HI >= LO ? HI - LO : 0);
-            d_notfast += wave_fast ? 0 : 1;
-            d_empty += HI < LO ? 1 : 0;
-        }
-#endif
-        int total = total_ahead;
-        if (i_start < LO || i_start > HI) {
-            // some lane's true starting index lies outside the slack of its count: those recount (a wave-local fixed point)
-            for (;;) {
-                const int ci = i_start - (incl - cnt);
-                if (__builtin_amdgcn_ballot_w64(!still_ok(ci)) == 0ull) break;
-#ifdef AURPPO_ACC_STAMPS
-                ++d_recount;
-#endif
-                cnt = eval(ci);
-                incl = wave_incl_scan(cnt);
-            }
-            total = __builtin_amdgcn_readlane(incl, kWave - 1);
-        }
-        const int cur_i0 = i_start - (incl - cnt);
-        const bool last = total >= i_start;           // every remaining index gets its target in this chunk
-        const bool dry = !last && cbase + kChunk >= avail;   // ... or the draws run out first: sticky error, everybody stops
-        if (lane == 0)
-            __hip_atomic_store(&s_conf[c % kWaves], pack(c, (last || dry) ? 0 : i_start - total), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_WORKGROUP);
-        __builtin_amdgcn_s_setprio(0);
-        DSTAMP(3);      // checked / recounted, confirmation published
-#ifdef AURPPO_ACC_STAMPS
-        ++d_chunks;
-        d_ready += have_start ? 1 : 0;
-#endif
-        // ---- off the chain: emit the targets
-        int consumed = kWpt;
-        if (!wave_fast || last) {
-            (void)walk(cur_i0, true, consumed);
-        } else {
-            const uint32_t mask = 0xffffffffu >> __clz(cur_i0 | 1);
-            const uint32_t lo = (uint32_t)(cur_i0 - kWpt);
-            int i = cur_i0;
-#pragma unroll
-            for (int u = 0; u < kWpt; ++u) {
-                const uint32_t v = y[u] & mask;
-                if (v <= lo) j[i--] = (int32_t)v;
-            }
-        }
-        DSTAMP(4);      // targets emitted
-        if (last || dry) {
-            // words consumed = everything up to and including the draw that filled i = 1
-            const bool mine = cnt > 0 && cur_i0 - cnt == 0;       // unique lane
-            const unsigned long long bm = __builtin_amdgcn_ballot_w64(mine);
-            long long words = dry ? (avail - cbase < kChunk ? avail - cbase : kChunk) : 0;
-            if (last) {
-                const int L = __builtin_ctzll(bm);
-                words = (long long)L * kWpt + __builtin_amdgcn_readlane(consumed, L);
-            }
-            if (lane == 0) {
-                posv[1] = cbase + words;
-                posv[done_slot] = cbase + words;
-                if (dry) posv[2] = 1;
-            }
-            break;
-        }
-    }
-#ifdef AURPPO_ACC_STAMPS
-    if (tid == 0) {
-        for (int k = 0; k < 5; ++k) posv[8 + k] = (long long)d_cyc[k];
-        posv[13] = (long long)d_chunks; posv[14] = (long long)d_recount; posv[15] = (long long)d_polls; posv[16] = (long long)d_ready;
-        posv[17] = (long long)d_absdelta; posv[18] = (long long)d_window; posv[19] = (long long)d_notfast; posv[20] = (long long)d_empty;
-    }
-#endif
-}
-
-// k_fy_accept3 -- the relay of k_fy_accept2 between WORKGROUPS, with k_fy_accept's fixed point inside each.
+// k_fy_accept3 -- a relay between WORKGROUPS, with k_fy_accept's fixed point inside each.  (A relay between the WAVES of one
+// workgroup, k_fy_accept2, was bit-exact and slower -- 515 us per shuffle against 394 -- and was retired in round 4: DESIGN 4.2c.)
 //
 // k_fy_accept is one workgroup walking the draw stream 8192 draws at a time: ~89 steps of ~4.6 us per 524 288-element shuffle,
 // every one on the chain (in-situ 437 us per shuffle, four per update: the longest pipeline of the update in round 3).  What a
@@ -1322,13 +1041,6 @@ static double need_words(int n) { return expected_draws(n) + 12.0 * sqrt(2.0 * (
 #define AURPPO_ACC_WPT 8      // draws per thread per accept step (A/B knob)
 #endif
 constexpr int kAccWpt = AURPPO_ACC_WPT;
-#ifndef AURPPO_ACC2_WAVES
-#define AURPPO_ACC2_WAVES 8   // waves of the relay (k_fy_accept2) -- A/B knobs
-#endif
-#ifndef AURPPO_ACC2_WPT
-#define AURPPO_ACC2_WPT 16    // draws per lane and chunk
-#endif
-constexpr int kAcc2Waves = AURPPO_ACC2_WAVES, kAcc2Wpt = AURPPO_ACC2_WPT;
 #ifndef AURPPO_ACC3_WPT
 #define AURPPO_ACC3_WPT 16    // draws per thread and chunk of the workgroup relay (k_fy_accept3): 16 384 per chunk (32: the kernel spills)
 #endif
@@ -1343,9 +1055,6 @@ static hipError_t own_cu_setup() {
 
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fy_accept<1024, kAccWpt>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kOwnCuLds);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fy_accept2<kAcc2Waves, kAcc2Wpt>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kOwnCuLds);
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fy_accept3<1024, kAcc3Wpt>),
@@ -1422,12 +1131,9 @@ int permute_once(aurppo_rng* rng, const int32_t* in, int32_t* out, int n, hipStr
         if (rng->acc_gen == 0) rng->acc_gen = 1;     // (0 is what the buffer is cleared to)
         hipLaunchKernelGGL((k_fy_accept3<1024, kAcc3Wpt>), dim3(G), dim3(1024), sizeof(int32_t) * kAcc3Chunk, s, rng->d_ring, (long long)rng->ring_cap,
                            rng->d_j[slot], n, rng->d_pos, 4 + slot, rng->d_relay, rng->relay_cap, rng->acc_gen);
-    } else if (aurppo_knobs().k2_accept == 1)
+    } else
         hipLaunchKernelGGL((k_fy_accept<1024, kAccWpt>), dim3(1), dim3(1024), kOwnCuLds, s, rng->d_ring, (long long)rng->ring_cap,
                            rng->d_j[slot], n, rng->d_pos, 4 + slot);
-    else
-        hipLaunchKernelGGL((k_fy_accept2<kAcc2Waves, kAcc2Wpt>), dim3(1), dim3(kAcc2Waves * 64), kOwnCuLds, s, rng->d_ring,
-                           (long long)rng->ring_cap, rng->d_j[slot], n, rng->d_pos, 4 + slot);
     AURPPO_LAUNCH_CHECK("k_fy_accept");
     AURPPO_HIP_TRY(hipEventRecord(rng->ev_acc[slot], s));
     // the link kernel also clears the heads of the NEXT shuffle (same n assumed; a larger one takes the path above).
@@ -1644,8 +1350,23 @@ extern "C" int aurppo_arange_i32(int32_t* idx, int n, void* stream) {
     return AURPPO_OK;
 }
 
+// The shuffle entry points keep host-side state per call (sequence number, multi-buffer slot, the relay's launch tag, what the
+// twist has been asked to stock) and work on the handle's own streams: a captured call would replay with a stale tag and stale
+// slots -- a wrong permutation with no error flag.  They therefore refuse a capturing stream (aurppo.h says so).
+static int refuse_capture(hipStream_t s, const char* who) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) {
+        (void)hipGetLastError();
+        return AURPPO_OK;          // (the legacy NULL stream cannot be queried while another stream captures: nothing to refuse)
+    }
+    AURPPO_REQUIRE(st == hipStreamCaptureStatusNone, AURPPO_EINVAL,
+                   "%s: the stream is being captured into a hipGraph; the mt19937 / shuffle entry points must run eagerly", who);
+    return AURPPO_OK;
+}
+
 extern "C" int aurppo_shuffle_i32(aurppo_rng* rng, int32_t* idx, int n, void* stream) {
     AURPPO_REQUIRE(rng, AURPPO_EINVAL, "aurppo_shuffle_i32: null handle");
+    if (int rc = refuse_capture((hipStream_t)stream, "aurppo_shuffle_i32")) return rc;
     if (n == 0) return AURPPO_OK;
     AURPPO_REQUIRE(idx, AURPPO_EINVAL, "aurppo_shuffle_i32: null pointer");
     AURPPO_REQUIRE(n >= 0 && n <= rng->max_n, AURPPO_ESHAPE, "aurppo_shuffle_i32: n=%d outside [0, max_n=%d]", n,
@@ -1665,6 +1386,7 @@ extern "C" int aurppo_shuffle_epochs_i32(aurppo_rng* rng, int32_t* out, int n, i
     AURPPO_REQUIRE(n >= 0 && n <= rng->max_n, AURPPO_ESHAPE, "aurppo_shuffle_epochs_i32: n=%d outside [0, max_n=%d]",
                    n, rng->max_n);
     AURPPO_REQUIRE(epochs >= 0, AURPPO_ESHAPE, "aurppo_shuffle_epochs_i32: epochs=%d negative", epochs);
+    if (int rc = refuse_capture((hipStream_t)stream, "aurppo_shuffle_epochs_i32")) return rc;
     if (n == 0 || epochs == 0) return AURPPO_OK;
     hipStream_t s = (hipStream_t)stream;
     if (n == 1) {

@@ -176,13 +176,22 @@ class FlatAdamMixin:
                 self.optimizer.load_state_dict(osd)
         elif "adam_m" not in ts and osd is not None and osd.get("state"):
             # saved by torch's per-parameter Adam (the CPU path, or upstream itself): re-home exp_avg / exp_avg_sq / step in the
-            # flat moment buffers K6b reads (state index = position in the param group = position in the bucket)
+            # flat moment buffers K6b reads.  ``state_dict()`` numbers a state entry by the parameter's position in the
+            # optimizer's param groups, which need not be the bucket's order (robot_ppo: actor first, then the rest)
+            pos, n_seen = {}, 0
+            for grp in self.optimizer.param_groups:
+                for q in grp["params"]:
+                    pos[id(q)] = n_seen
+                    n_seen += 1
             with torch.no_grad():
                 off, step = 0, 0.0
-                for i, p in enumerate(self.bucket.params):
+                for p in self.bucket.params:
                     k = p.numel()
-                    st = osd["state"].get(i)
+                    st = osd["state"].get(pos.get(id(p), -1))
                     if st is not None:
+                        if st["exp_avg"].numel() != k or st["exp_avg_sq"].numel() != k:
+                            raise RuntimeError(f"optimizer_state entry {pos[id(p)]} has {st['exp_avg'].numel()} elements, "
+                                               f"the parameter it belongs to has {k}")
                         self._adam_m[off:off + k].copy_(st["exp_avg"].reshape(-1))
                         self._adam_v[off:off + k].copy_(st["exp_avg_sq"].reshape(-1))
                         step = max(step, float(st["step"]))

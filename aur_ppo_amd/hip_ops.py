@@ -346,6 +346,26 @@ def mlp_step_flops(layout, M):
     return 2 * total * M
 
 
+def reload_knobs():
+    """Make the library re-read its AURPPO_* environment knobs now (it reads them once per process otherwise)."""
+    _check(_lib_or_raise().aurppo_reload_knobs(), "aurppo_reload_knobs")
+
+
+def mlp_step_issued_bf16_flops(layout, M):
+    """bf16 MFMA FLOPs k_mlp_step3 ISSUES per launch (csrc/mlp3.hip): every fp32 product is six bf16 products (bf16x3.h), the
+    heads are padded to 16 outputs, the state to a multiple of 16 columns.  Per 32-row tile and wave (net, column half cb):
+    v_mfma_f32_32x32x16_bf16 (32 768 FLOP): F1 6 x ceil(D / 16), F2 24, dH2 6, dW2 + dH1 48, dW1 24 (if cb * 32 < D);
+    v_mfma_f32_16x16x32_bf16 (16 384 FLOP): head 12, dW3 12.  None for K7w / the fp32-MFMA build (they issue fp32 MFMAs)."""
+    if layout.get("wide"):
+        return None
+    D = layout["D"]
+    nks1 = (D + 15) // 16
+    n32 = sum(6 * nks1 + 24 + 6 + 48 + (24 if cb * 32 < D else 0) for _net in range(2) for cb in range(2))
+    n16 = 4 * 24
+    tiles = (M + 31) // 32
+    return tiles * (n32 * 32768 + n16 * 16384)
+
+
 def _wide_only_step(layout, who):
     if layout.get("wide"):
         raise ValueError(f"{who}: only the default 64-64 MLP has the chained minibatch kernels; this policy "

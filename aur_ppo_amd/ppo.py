@@ -213,7 +213,31 @@ class ppo(FlatAdamMixin):
 
     # ------------------------------------------------------------------ rollout (src/ppo.py:103-123)
     def make_env(self, gym_id, idx, capture_video):
-        raise NotImplementedError("environments are built by aur_ppo_amd.envs.make_vec_env")
+        """Thunk that builds one wrapped gym environment (src/ppo.py:85-99): episode statistics always, video recording for
+        env 0 when asked, and for continuous control the clip-action / normalise / clip observation and reward wrappers in
+        upstream's order.  Needs ``gym`` (or ``gymnasium``), which this image does not ship: the thunk is returned either
+        way, as upstream's is, and raises ImportError when CALLED without it (the synthetic device-resident envs of
+        ``aur_ppo_amd.envs.make_vec_env`` are what ``train()`` uses then)."""
+        def thunk():
+            try:
+                import gym
+            except ImportError:
+                try:
+                    import gymnasium as gym
+                except ImportError as e:
+                    raise ImportError("ppo.make_env: neither gym nor gymnasium is importable; use aur_ppo_amd.envs.make_vec_env") from e
+            env = gym.make(gym_id)
+            env = gym.wrappers.RecordEpisodeStatistics(env)
+            if capture_video and idx == 0:
+                env = gym.wrappers.RecordVideo(env, f"videos/{self.run_name}")
+            if self.continuous:
+                env = gym.wrappers.ClipAction(env)
+                env = gym.wrappers.NormalizeObservation(env)
+                env = gym.wrappers.TransformObservation(env, lambda obs: np.clip(obs, -10, 10))
+                env = gym.wrappers.NormalizeReward(env)
+                env = gym.wrappers.TransformReward(env, lambda reward: np.clip(reward, -10, 10))
+            return env
+        return thunk
 
     def rewards_to_go(self, step, next_obs, global_step, writer):
         if self._mlp is not None and hasattr(self.ops, "mlp_act"):

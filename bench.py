@@ -28,13 +28,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-os.environ.setdefault("AURPPO_TEST_KNOBS", "1")   # the library re-reads AURPPO_K7_VARIANT per call: the plain-fp32 K7 is timed beside the default one
-
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 MFMA peak (same guide, matrix cores table)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (same table: ~2.5 PF; never the 2:1-sparsity figure)
 
 
 def parse():
@@ -475,17 +474,33 @@ def main():
     env_steps = world * N * T * args.steps
     M = agent.minibatch_size
 
+    traffic_src = {}
+
     def pmc(name, key=None):
         """PMC bytes per launch, collected (separate --pmc passes) on the default workload only (``key``: the net shape of
-        a K7w run, for which only some shapes were collected)."""
+        a K7w run, for which only some shapes were collected).  Not measured in THIS run: ``traffic_source`` names the
+        committed file and the commit it was last changed in; any other workload gets null."""
         if (M, Dm, A) != (131072, 64, 6):
+            traffic_src["why_null"] = "PMC passes were collected at M=131072, D=64, A=6 only"
             return None
         path = os.path.join(ROOT, "profiles", name)
         try:
             d = json.load(open(path))
-            return (d[key] if key else d).get("hbm_bytes_per_launch")
-        except Exception:
+            val = (d[key] if key else d).get("hbm_bytes_per_launch")
+        except Exception as e:
+            traffic_src["why_null"] = f"profiles/{name}: {e}"
             return None
+        traffic_src["file"] = f"profiles/{name}" + (f"[{key}]" if key else "")
+        try:
+            import subprocess
+            traffic_src["git_sha"] = subprocess.run(["git", "-C", ROOT, "log", "-n", "1", "--format=%h", "--", path],
+                                                    capture_output=True, text=True, timeout=10).stdout.strip() or None
+        except Exception:
+            traffic_src["git_sha"] = None
+        if not traffic_src["git_sha"]:      # (the GPU box gets a snapshot without .git: the file names the commit it was collected at)
+            traffic_src["git_sha"] = (d[key] if key else d).get("collected_at_commit") or d.get("collected_at_commit")
+        traffic_src["how"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this bench (tools/collect_profiles.sh), FETCH_SIZE x 2 (gfx950)"
+        return val
 
     B = N * T
     bytes_8d = (20 + args.epochs * (8 * Dm + 8 * A + 84)) * B            # SURVEY 8d: 2 596 B/env-step at D=64, A=6, E=4
@@ -524,15 +539,36 @@ def main():
                     "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
                     "traffic": (pmc("mlp_wide_pmc.json", f"{args.num_layers}x{args.hidden_dim}") if agent._mlp.get("wide")
                                 else pmc("mlp3_pmc.json" if k7_variant == 3 else "mlp_pmc.json")),
+                    "traffic_source": traffic_src,
                     "flops_per_launch": flops, "avg_launch_us": round(ms * 1e3, 2), "launches_timed": len(mlp_events),
                     "algorithmic_hbm_bytes_per_launch": M * (4 * (Dm + A + 4) + 4),
                     "how": f"hipEvent pair recorded inside the library around the K7 kernel, one extra stand-alone "
                            f"launch every {run['every']}th step on the update's own minibatch"
                            + (" (the update itself is a hipGraph)" if agent._graph is not None else "")}
         if k7_variant != 2 and not agent._mlp.get("wide"):
+            # The kernel runs on the BF16 matrix pipe: six bf16 products per fp32 product.  The roof it is held to is that
+            # pipe's (2.5 PFLOP/s dense): `achieved` = 6 x the algorithmic fp32 FLOPs / duration, `frac` against 2 500; the
+            # same FLOPs priced at the fp32 MFMA peak (a speed-up statement, not a roofline: it can exceed 1) moves to
+            # `vs_fp32_mfma`; `pipe` counts what the kernel actually ISSUES (padding included), the number the
+            # SQ_VALU_MFMA_BUSY_CYCLES counter of profiles/r04/mlp3_mfma_pmc.json checks.
+            issued = H.mlp_step_issued_bf16_flops(agent._mlp, M)
+            roofline["vs_fp32_mfma"] = {"achieved": roofline["achieved"], "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                        "frac": roofline["frac"],
+                                        "what": "the algorithmic fp32 FLOPs priced at the fp32 MFMA peak the kernel does NOT run on"}
+            ach6 = 6.0 * flops / (ms * 1e-3) / 1e12
+            roofline.update(achieved=round(ach6, 1), peak=MFMA_BF16_PEAK_TFLOPS, frac=round(ach6 / MFMA_BF16_PEAK_TFLOPS, 4),
+                            dtype_of_peak="bf16 MFMA dense (each fp32 product = 6 bf16 products, fp32 accumulate)")
+            ach_i = issued / (ms * 1e-3) / 1e12
+            roofline["pipe"] = {"issued_bf16_flops_per_launch": issued, "achieved": round(ach_i, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+                                "unit": "TFLOP/s", "frac": round(ach_i / MFMA_BF16_PEAK_TFLOPS, 4),
+                                "padding_over_6x_algorithmic": round(issued / (6.0 * flops), 4),
+                                "what": "bf16 MFMA FLOPs the kernel issues per launch (6 x useful + head padded to 16 outputs; "
+                                        "hip_ops.mlp_step_issued_bf16_flops) / duration / 2 500 TFLOP/s; counter check: "
+                                        "profiles/r04/mlp3_mfma_pmc.json"}
             # the plain-fp32 number beside it: the same minibatch through k_mlp_step2 (v_mfma_f32_32x32x2_f32), stand-alone launches
             prev = os.environ.get("AURPPO_K7_VARIANT")
             os.environ["AURPPO_K7_VARIANT"] = "2"
+            H.reload_knobs()
             try:
                 evs = []
                 for _ in range(6):
@@ -549,9 +585,9 @@ def main():
                     os.environ.pop("AURPPO_K7_VARIANT", None)
                 else:
                     os.environ["AURPPO_K7_VARIANT"] = prev
+                H.reload_knobs()
             roofline["arithmetic"] = ("fp32 operands as three bf16 planes each, six v_mfma_f32_32x32x16_bf16 products per "
-                                      "K = 16 (dropped terms <= 2^-24 relative), fp32 accumulate; `peak` stays the fp32 MFMA "
-                                      "peak the same FLOPs would be priced at on v_mfma_f32_32x32x2_f32")
+                                      "K = 16 (dropped terms <= 2^-24 relative), fp32 accumulate; `peak` is the bf16 pipe's")
     elif probe.pairs:
         gather_bytes = M * (8 * Dm + 8 * A + 36)          # idx + 6 streams read + written
         g_ms = probe.mean_ms()
@@ -591,7 +627,9 @@ def main():
                       "minibatch_step": ("K3 + torch nets + K5" if agent._mlp is None else
                                          "K7w fused MLP step + K6b" if agent._mlp.get("wide") else
                                          f"K7 fused MLP step (variant {k7_variant})")},
-           "roofline": roofline}
+           "roofline": roofline,
+           # a capture that raised leaves the update running eagerly on every rank: said HERE, not only inside config
+           "graph_fallback": (agent.graph_fallback[:200] if agent.graph_fallback else None)}
     parity = None
     if world == 1 and not args.force_dp and args.cpu_baseline_updates > 0:
         out["cpu_baseline"], parity = cpu_baseline(args, run["data"], run["init_sd"], args.cpu_baseline_updates, run["gpu_first"])

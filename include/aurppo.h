@@ -12,7 +12,10 @@
  *     torch_buffer (src/ppo.py:24-29) and of buffer.flatten() (src/ppo.py:32-39).
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls enqueue and
  *     return; they never allocate, never synchronise (except the *_get_state/_set_state helpers).
- *     All entry points are safe to capture into a hipGraph.
+ *     All entry points are safe to capture into a hipGraph EXCEPT the aurppo_mt19937_* / aurppo_shuffle_* family: a
+ *     generator handle carries host-side sequence state and its own side streams, so those calls must run eagerly
+ *     (aurppo_shuffle_*_i32 return AURPPO_EINVAL on a capturing stream); the trainer runs them on a side stream, one
+ *     update ahead of the captured graph that reads their output.
  *   - Return 0 on success, <0 on error; aurppo_last_error() gives a thread-local message.
  *   - The caller owns all tensors.  The library owns only RNG handles.
  *   - No CPU fallbacks exist in this library: without a gfx950 device every compute call fails.
@@ -68,6 +71,9 @@ int aurppo_device_count(void);
  * AURPPO_K7_VARIANT overrides the built-in default.  (No reference counterpart: the policy nets are torch modules
  * there, src/models/actor_critic.py:8-51.) */
 int aurppo_k7_variant(void);
+/* The library reads its AURPPO_* environment knobs once per process; this re-reads them now (diagnostics: bench.py switches
+ * AURPPO_K7_VARIANT after its timed region to time the fp32-MFMA build beside the default).  Returns 0. */
+int aurppo_reload_knobs(void);
 
 /* ---- K1: advantage estimation -------------------------------------------------------------
  * Replaces ppo.run_gae / ppo.normal_advantage (src/ppo.py:125-157; duplicates in

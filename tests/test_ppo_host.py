@@ -36,7 +36,7 @@ def test_api_surface_matches_reference():
     for attr in ("all_steps", "batch_size", "minibatch_size", "num_updates", "run_name", "envs", "state_dim",
                  "action_dim", "policy", "buffer", "optimizer", "total_returns", "total_episode_lengths", "x_indices"):
         assert hasattr(a, attr), attr
-    for m in ("rewards_to_go", "run_gae", "normal_advantage", "advantages", "train", "plot", "moving_average",
+    for m in ("make_env", "rewards_to_go", "run_gae", "normal_advantage", "advantages", "train", "plot", "moving_average",
               "plot_episodic_returns"):
         assert callable(getattr(a, m)), m
     assert (a.batch_size, a.minibatch_size, a.num_updates) == (128, 32, 2)
@@ -49,6 +49,44 @@ def test_api_surface_matches_reference():
     b = a.buffer.flatten(torch.zeros(16, 8), torch.ones(16, 8))
     assert [tuple(t.shape) for t in b] == [(128, 4), (128,), (128,), (128,), (128,), (128,)]
     assert b[0].data_ptr() == a.buffer.states.data_ptr()      # views, not copies
+
+
+def test_make_env_returns_the_reference_thunk(monkeypatch):
+    """src/ppo.py:85-99: make_env returns a thunk; calling it wraps gym.make(gym_id) with RecordEpisodeStatistics, RecordVideo for
+    env 0 when asked, and -- continuous control only -- ClipAction, NormalizeObservation, TransformObservation, NormalizeReward,
+    TransformReward, in that order.  gym is not in this image: a recording stand-in module checks the order."""
+    import sys
+    import types
+    calls = []
+
+    def wrapper(name):
+        def w(env, *a):
+            calls.append(name)
+            return ("wrapped", name, env)
+        return w
+    fake = types.ModuleType("gym")
+    fake.make = lambda gid: (calls.append(f"make:{gid}"), ("env", gid))[1]
+    fake.wrappers = types.SimpleNamespace(**{n: wrapper(n) for n in ("RecordEpisodeStatistics", "RecordVideo", "ClipAction",
+                                                                       "NormalizeObservation", "TransformObservation",
+                                                                       "NormalizeReward", "TransformReward")})
+    a = ppo(_params(), ops=oracle_ops)
+    thunk = a.make_env("CartPole-v1", 0, True)
+    assert callable(thunk) and calls == []            # nothing is built until the thunk runs
+    monkeypatch.setitem(sys.modules, "gym", fake)
+    thunk()
+    assert calls == ["make:CartPole-v1", "RecordEpisodeStatistics", "RecordVideo"]
+    calls.clear()
+    a.make_env("CartPole-v1", 1, True)()
+    assert calls == ["make:CartPole-v1", "RecordEpisodeStatistics"]
+    calls.clear()
+    a.continuous = True
+    a.make_env("Hopper-v4", 1, False)()
+    assert calls == ["make:Hopper-v4", "RecordEpisodeStatistics", "ClipAction", "NormalizeObservation", "TransformObservation",
+                     "NormalizeReward", "TransformReward"]
+    monkeypatch.delitem(sys.modules, "gym")
+    monkeypatch.setitem(sys.modules, "gymnasium", None)
+    with pytest.raises(ImportError):
+        a.make_env("CartPole-v1", 0, False)()
 
 
 @pytest.mark.parametrize("name", ["cfg1_discrete", "cfg2_continuous", "cfg3_normal_adv_tail", "cfg4_normal_adv_tail_clipv",

@@ -28,7 +28,7 @@ buf = (C.c_longlong * 24)()
 lib.aurppo_debug_accept_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
 assert lib.aurppo_debug_accept_stamps(rng._h, buf) == 0
 v = list(buf)
-if os.environ.get("AURPPO_K2_ACCEPT", "3") == "3":
+if os.environ.get("AURPPO_K2_ACCEPT", "3") != "1":
     names3 = ["draws + next fetch + reference", "solve from the guess", "list the sensitive draws", "wait for the predecessor", "walk the list + publish",
               "redo counts from the true start", "emit targets"]
     ch = max(v[7], 1)
@@ -37,15 +37,6 @@ if os.environ.get("AURPPO_K2_ACCEPT", "3") == "3":
           f"mean |true - guessed start| {v[11] / ch:.1f}, W {v[13] / ch:.0f}, rounds {v[12]} ({v[12] / ch:.1f} per chunk); {tot} cycles")
     for k, nm in enumerate(names3):
         print(f"  {nm:34s} {v[k]:10d} cycles  {100 * v[k] / tot:5.1f} %   {v[k] / ch:8.0f} per chunk")
-    sys.exit(0)
-if os.environ.get("AURPPO_K2_ACCEPT", "2") != "1":
-    names2 = ["wait draws + issue next fetch", "ahead-of-time evaluation", "wait for the predecessor", "check / recount / publish", "emit targets"]
-    ch = max(v[5], 1)
-    tot = sum(v[:5])
-    print(f"k_fy_accept2, wave 0: {v[5]} chunks, {v[6]} recount rounds, {v[7]} polls, predecessor already confirmed at peek time: {v[8]}; {tot} cycles")
-    print(f"  guess: mean |true - guessed start| {v[9] / ch:.1f}, mean width of the validity range {v[10] / ch:.1f}, chunks with a lane on the literal rule {v[11]}, empty ranges {v[12]}")
-    for k, nm in enumerate(names2):
-        print(f"  {nm:32s} {v[k]:10d} cycles  {100 * v[k] / tot:5.1f} %   {v[k] / ch:8.0f} per chunk")
     sys.exit(0)
 names = ["wait draws", "issue next fetch", "first guess run", "rounds: combine + recount", "emit run", "bookkeeping", "rounds: scan + publish", "rounds: barrier"]
 steps, iters = v[8], v[9]

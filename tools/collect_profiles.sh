@@ -8,7 +8,7 @@
 #   bench_nofused_*.json/csv            bench.py --no-fused-mlp (per-op path: K1, K3, K4+K5, K6b stand-alone durations)
 #   bench_forcedp_*.json/csv            bench.py --force-dp (the W > 1 launch path captured around a one-rank RCCL all-reduce)
 #   mlp3_pmc.json                       separate --pmc passes for the default K7 kernel's (k_mlp_step3) HBM traffic; mlp_pmc.json: k_mlp_step2's
-#   k7_stamps_v{2,3,4}.txt              in-kernel phase stamps of the three K7 builds (tools/mlp_stamps.py); k7_time.txt: stand-alone launch times
+#   k7_stamps_v{3,2}.txt                in-kernel phase stamps of the two K7 builds (tools/mlp_stamps.py); k7_time.txt: stand-alone launch times
 #   k2_stamps.txt, k2_time.txt          accept-kernel stamps and the shuffle pipeline's stand-alone time for both accept kernels
 #   bench_wide_{3x128,3x64,2x128}*.json/csv   bench.py --hidden-dim/--num-layers (K7w / K8w), plain and under rocprofv3
 #   wide_bench.json                     tools/bench_wide.py: K7w / K8w against the per-op path over the -d / -nl shapes
@@ -45,11 +45,16 @@ for shape in "128 3" "64 3" "128 2"; do
   run 600 python3 $R/bench.py --hidden-dim $1 --num-layers $2 --steps 30 --cpu-baseline-updates 1 > $O/bench_wide_$2x$1.json 2> $O/bench_wide_$2x$1.err
 done
 run 600 python3 $R/tools/bench_wide.py > $O/wide_bench.json 2> $O/wide_bench.err
-for v in 2 3 4; do AURPPO_K7_VARIANT=$v run 300 python3 $R/tools/mlp_stamps.py > $O/k7_stamps_v$v.txt 2>&1; done
-(for m in 131072 16384; do for v in 3 2 4; do K7_M=$m AURPPO_K7_VARIANT=$v python3 $R/tools/k7_time.py 2>&1 | tail -1; done; done) > $O/k7_time.txt
-(for a in 3 1 2; do AURPPO_K2_ACCEPT=$a python3 $R/tools/k2_time.py 2>&1 | tail -1; done) > $O/k2_time.txt
-(AURPPO_K2_ACCEPT=3 python3 $R/tools/accept_stamps.py 2>&1 | tail -9; AURPPO_K2_ACCEPT=1 python3 $R/tools/accept_stamps.py 2>&1 | tail -10; AURPPO_K2_ACCEPT=2 python3 $R/tools/accept_stamps.py 2>&1 | tail -8) > $O/k2_stamps.txt
-(K7_M=16384 AURPPO_K7_VARIANT=3 python3 $R/tools/mlp_stamps.py 2>&1 | tail -20) > $O/k7_stamps_v3_M16384.txt
+# (every step below runs under `run`, i.e. its own timeout; a pipe into tail would swallow its exit code, so outputs go to files first)
+for v in 3 2; do AURPPO_K7_VARIANT=$v run 300 python3 $R/tools/mlp_stamps.py > $O/k7_stamps_v$v.txt 2>&1; done
+: > $O/k7_time.txt
+for m in 131072 16384; do for v in 3 2; do K7_M=$m AURPPO_K7_VARIANT=$v run 300 python3 $R/tools/k7_time.py > $O/.step.txt 2>&1; tail -1 $O/.step.txt >> $O/k7_time.txt; done; done
+: > $O/k2_time.txt
+for a in 3 1; do AURPPO_K2_ACCEPT=$a run 300 python3 $R/tools/k2_time.py > $O/.step.txt 2>&1; tail -1 $O/.step.txt >> $O/k2_time.txt; done
+: > $O/k2_stamps.txt
+for a in 3 1; do AURPPO_K2_ACCEPT=$a run 300 python3 $R/tools/accept_stamps.py > $O/.step.txt 2>&1; tail -10 $O/.step.txt >> $O/k2_stamps.txt; done
+K7_M=16384 AURPPO_K7_VARIANT=3 run 300 python3 $R/tools/mlp_stamps.py > $O/.step.txt 2>&1; tail -20 $O/.step.txt > $O/k7_stamps_v3_M16384.txt
+rm -f $O/.step.txt
 cd /tmp
 pmc() {  # pmc <variant> <kernel> <out>
   rm -rf $O/pmc_fetch $O/pmc_write

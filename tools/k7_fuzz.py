@@ -17,7 +17,7 @@ for case in range(n_cases):
     B = T * N
     M = random.choice([1, 2, 31, 32, 33, 63, 64, 65, 100, 255, 256, 257, 1000, B // 4, B // 2, B])
     M = max(1, min(M, B))
-    os.environ["AURPPO_K7_VARIANT"] = random.choice(["2", "3", "3", "4"])
+    os.environ["AURPPO_K7_VARIANT"] = random.choice(["2", "3", "3"])
     norm_adv = random.random() < 0.7 and M > 1
     vmode = random.choice([0, 1, 2])
     packed = (A if cont else 1) <= 12 and random.random() < 0.5

@@ -26,21 +26,8 @@ for _ in range(3):
 torch.cuda.synchronize()
 ws = H._ws_cache[("mlp", torch.cuda.current_device())]
 off = ((8 * (2 * 256 + 8 * 256) + 4 * 256 * n + 63) // 64) * 64
-if os.environ.get("AURPPO_K7_VARIANT") == "4":
-    raw = ws[off:off + 8 * 40 * 256].view(torch.int64).view(256, 40).cpu().numpy().astype(np.float64)
-    raw = raw[(raw[:, 12] > 0) & (raw[:, 12] < 100)]
-    cyc, ticks = np.median(raw[:, 32]), np.median(raw[:, 33])
-    print(f"k_mlp_step4, wave 0 of {raw.shape[0]} workgroups: tile loop {cyc:.0f} cycles in {ticks:.0f} ticks of the 100 MHz clock = {cyc / ticks * 0.1:.2f} GHz; "
-          f"{np.median(raw[:, 12]):.1f} tiles per wave (median)")
-    names = ["X split + image", "F1 (both blocks) + epilogue 0", "F2 + epilogue 1 of F1, 0 of F2", "F3 + epilogue 1 of F2", "loss + dOut",
-             "dH2, dW3, dZ2", "dH1 block 0, dW2", "dH1 block 1, dZ1", "fetch + dW1"]
-    per = raw[:, :9] / raw[:, 12:13]
-    med = np.median(per, axis=0)
-    for k, nm in enumerate(names):
-        print(f"   {nm:34s} {med[k]:9.0f} cycles per tile ({100 * med[k] / med.sum():5.1f} %)")
-    print(f"   {'total':34s} {med.sum():9.0f} cycles per tile")
-elif True:
-    if os.environ.get("AURPPO_K7_VARIANT") == "3":
+if True:
+    if os.environ.get("AURPPO_K7_VARIANT", "3") != "2":
         x = ws[off + 8 * 40 * 256:off + 8 * 44 * 256].view(torch.int64).view(256, 4).cpu().numpy().astype(np.float64)
         x = x[x[:, 0] > 0]
         m = np.median(x, axis=0)

@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/ramp
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $O/tr -- python3 $R/bench.py --steps 20 --warmup 3 --cpu-baseline-updates 0 --no-parity --shard-envs-per-gpu 0 --no-probe > $O/out.json 2> $O/err.txt
+timeout -k 10 600 rocprofv3 --kernel-trace --output-format csv -d $O/tr -- python3 $R/bench.py --steps 20 --warmup 3 --cpu-baseline-updates 0 --no-parity --shard-envs-per-gpu 0 --no-probe > $O/out.json 2> $O/err.txt || { echo "bench.py under rocprofv3 failed or timed out (rc $?)" >&2; exit 1; }
 python3 - <<PY
 import csv, glob
 f = glob.glob("$O/tr/*/*kernel_trace.csv")[0]
