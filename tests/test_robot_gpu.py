@@ -211,4 +211,4 @@ def test_reference_format_checkpoint_rehomes_adam_moments_by_optimizer_order(tmp
         # and the torch optimizer's own view of the state is that slice
         assert b.optimizer.state[q]["exp_avg"].data_ptr() == b._adam_m[off:off + k].data_ptr()
         off += k
-    assert float(b._adam_t) == 7.0 and abs(b.get_lr() - 1e-4) < 1e-12
+    assert float(b._adam_t) == 7.0 and abs(b.get_lr() - 1e-4) < 1e-9      # (an fp32 device scalar)

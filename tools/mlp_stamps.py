@@ -9,7 +9,7 @@ so = "/tmp/libaurppo_stamps.so"
 csrc = os.path.join(ROOT, "aur_ppo_amd", "csrc")
 import __graft_entry__ as g
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-                "-DAURPPO_MLP_STAMPS"] + [os.path.join(csrc, f) for f in g.HIP_SOURCES] + ["-o", so], check=True)
+                "-DAURPPO_MLP_STAMPS"] + os.environ.get("AURPPO_EXTRA_DEFS", "").split() + [os.path.join(csrc, f) for f in g.HIP_SOURCES] + ["-o", so], check=True)
 from aur_ppo_amd import _lib, hip_ops as H
 _lib.LIB_PATH = so
 _lib._lib = None
