@@ -14,7 +14,8 @@ SYMBOLS = (
     "aurppo_mt19937_set_state", "aurppo_mt19937_status_f32", "aurppo_arange_i32", "aurppo_shuffle_i32", "aurppo_shuffle_epochs_i32",
     "aurppo_gather_f32", "aurppo_loss_workspace_bytes", "aurppo_loss_fwd_bwd_f32", "aurppo_loss_fwd_bwd_packed_f32",
     "aurppo_clip_workspace_bytes", "aurppo_grad_norm_clip_f32", "aurppo_mlp_workspace_bytes", "aurppo_mlp_ppo_step_f32",
-    "aurppo_mlp_ppo_step_ev_f32", "aurppo_mlp_ppo_minibatch_f32", "aurppo_mlp_ppo_grad_f32", "aurppo_mlp_ppo_apply_f32", "aurppo_pack_records_f32", "aurppo_mlp_act_f32", "aurppo_clip_adam_f32",
+    "aurppo_mlp_ppo_step_ev_f32", "aurppo_mlp_ppo_minibatch_f32", "aurppo_mlp_ppo_grad_f32", "aurppo_mlp_ppo_apply_f32", "aurppo_mlp_ppo_apply_parts_f32", "aurppo_p2p_handle_bytes", "aurppo_p2p_parts", "aurppo_p2p_create",
+    "aurppo_p2p_get_handle", "aurppo_p2p_open_peers", "aurppo_p2p_allreduce_mean_f32", "aurppo_p2p_status", "aurppo_p2p_destroy", "aurppo_pack_records_f32", "aurppo_mlp_act_f32", "aurppo_clip_adam_f32",
     "aurppo_bias_relu_pool2_fwd_f32", "aurppo_bias_relu_pool2_bwd_f32", "aurppo_weighted_batch_sum_f32",
     "aurppo_first_block_fwd_f32", "aurppo_first_block_bwd_f32",
     "aurppo_mlp_wide_workspace_bytes", "aurppo_mlp_wide_ppo_step_f32", "aurppo_mlp_wide_ppo_minibatch_f32",
@@ -77,6 +78,14 @@ def load() -> C.CDLL:
     lib.aurppo_mlp_ppo_step_ev_f32.argtypes = lib.aurppo_mlp_ppo_step_f32.argtypes + [vp, vp]
     lib.aurppo_mlp_ppo_grad_f32.argtypes = [vp] * 4 + [i32] * 5 + [vp, C.POINTER(i32), i32, vp, f64, f64, f64, i32, i32, vp, vp, i32, vp, vp]
     lib.aurppo_mlp_ppo_apply_f32.argtypes = [vp] * 4 + [C.POINTER(i32), i32, i32, f64, f64, vp, vp, f64, f64, f64, vp, vp, i32, vp, i32, vp, vp]
+    lib.aurppo_mlp_ppo_apply_parts_f32.argtypes = [vp] * 4 + [C.POINTER(i32), i32, i32, vp, i32, f64, vp, vp, f64, f64, f64, vp, vp, i32, vp, i32, vp, vp]
+    lib.aurppo_p2p_parts.argtypes = [i32]
+    lib.aurppo_p2p_create.argtypes = [C.POINTER(vp), i32, i32, i32, vp]
+    lib.aurppo_p2p_get_handle.argtypes = [vp, vp]
+    lib.aurppo_p2p_open_peers.argtypes = [vp, vp]
+    lib.aurppo_p2p_allreduce_mean_f32.argtypes = [vp, vp, i32, vp, vp, f64, vp]
+    lib.aurppo_p2p_status.argtypes = [vp, C.POINTER(i32), vp]
+    lib.aurppo_p2p_destroy.argtypes = [vp]
     lib.aurppo_pack_records_f32.argtypes = [vp, vp, i32, i32, vp, vp]
     lib.aurppo_mlp_ppo_minibatch_f32.argtypes = ([vp] * 4 + [i32] * 5 + [vp, C.POINTER(i32), i32, vp, f64, f64, f64, i32, i32, vp] +
                                                  [vp, vp, f64, vp, vp, f64, f64, f64, vp, vp, i32, i32, vp, vp])

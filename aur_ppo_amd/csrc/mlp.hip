@@ -716,11 +716,10 @@ extern "C" int aurppo_mlp_ppo_grad_f32(const float* obs, const float* actions, c
                          vf_coef, norm_adv, vloss_mode, out_scalars, workspace, stream, nullptr, nullptr, &c);
 }
 
-extern "C" int aurppo_mlp_ppo_apply_f32(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const int* layout_h,
-                                        int n_params, int D, double grad_scale, double max_norm, const float* lr_dev,
-                                        const float* step_dev, double beta1, double beta2, double eps, float* out_norm,
-                                        const float* rec, int rec_floats, const int32_t* next_idx, int next_M,
-                                        void* workspace, void* stream) {
+static int mlp_apply_impl(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const int* layout_h, int n_params, int D,
+                          double grad_scale, const double* sq_part, int n_part, double max_norm, const float* lr_dev,
+                          const float* step_dev, double beta1, double beta2, double eps, float* out_norm, const float* rec,
+                          int rec_floats, const int32_t* next_idx, int next_M, void* workspace, void* stream) {
     AURPPO_REQUIRE(params && grads && exp_avg && exp_avg_sq && layout_h && lr_dev && step_dev && out_norm && workspace,
                    AURPPO_EINVAL, "aurppo_mlp_ppo_apply_f32: null pointer");
     AURPPO_REQUIRE(n_params > 0 && D >= 1 && D <= H, AURPPO_ESHAPE, "aurppo_mlp_ppo_apply_f32: n_params=%d D=%d",
@@ -742,12 +741,31 @@ extern "C" int aurppo_mlp_ppo_apply_f32(float* params, float* grads, float* exp_
                               aurppo_knobs().k7_variant == 3 ? wv.wop3 : (unsigned short*)nullptr, {}};
     oc_apply.wide.wop = nullptr;
     hipLaunchKernelGGL(k_adam_chain, dim3(nb_upd + nsb), dim3(kThreads), 0, (hipStream_t)stream, params, grads, exp_avg,
-                       exp_avg_sq, n_params, (const double*)nullptr, 0, (float)max_norm, lr_dev, step_dev, beta1, beta2, eps,
+                       exp_avg_sq, n_params, sq_part, sq_part ? n_part : 0, (float)max_norm, lr_dev, step_dev, beta1, beta2, eps,
                        out_norm, (float)grad_scale, nb_upd, oc_apply,
                        reinterpret_cast<const float4*>(rec), rec_floats == 16 ? 4 : 1, next_idx, next_idx ? next_M : 0,
                        reinterpret_cast<double (*)[2]>(stats), (const double*)nullptr);
     AURPPO_LAUNCH_CHECK("k_adam_chain");
     return AURPPO_OK;
+}
+
+extern "C" int aurppo_mlp_ppo_apply_f32(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const int* layout_h,
+                                        int n_params, int D, double grad_scale, double max_norm, const float* lr_dev,
+                                        const float* step_dev, double beta1, double beta2, double eps, float* out_norm,
+                                        const float* rec, int rec_floats, const int32_t* next_idx, int next_M,
+                                        void* workspace, void* stream) {
+    return mlp_apply_impl(params, grads, exp_avg, exp_avg_sq, layout_h, n_params, D, grad_scale, nullptr, 0, max_norm, lr_dev, step_dev,
+                          beta1, beta2, eps, out_norm, rec, rec_floats, next_idx, next_M, workspace, stream);
+}
+
+extern "C" int aurppo_mlp_ppo_apply_parts_f32(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const int* layout_h,
+                                              int n_params, int D, const double* sq_part, int n_part, double max_norm,
+                                              const float* lr_dev, const float* step_dev, double beta1, double beta2, double eps,
+                                              float* out_norm, const float* rec, int rec_floats, const int32_t* next_idx,
+                                              int next_M, void* workspace, void* stream) {
+    AURPPO_REQUIRE(sq_part && n_part > 0, AURPPO_EINVAL, "aurppo_mlp_ppo_apply_parts_f32: no partial sums");
+    return mlp_apply_impl(params, grads, exp_avg, exp_avg_sq, layout_h, n_params, D, 1.0, sq_part, n_part, max_norm, lr_dev, step_dev,
+                          beta1, beta2, eps, out_norm, rec, rec_floats, next_idx, next_M, workspace, stream);
 }
 
 namespace {

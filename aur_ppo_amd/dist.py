@@ -74,6 +74,29 @@ def allreduce_sum_(flat, world=None, force=False):
     return flat
 
 
+def allreduce_choice():
+    """Which exchange carries the MLP policy's gradient bucket between ranks: ``"rccl"`` (default: ``torch.distributed``'s
+    all-reduce, a ring / tree over xGMI) or ``"p2p"`` (``AURPPO_DP_ALLREDUCE=p2p``: the one-shot exchange over HIP-IPC peer
+    memory of csrc/p2p.hip -- one launch, one hop, no collective library on the path; SURVEY 8e's plan B for a 68 KB
+    message).  Buckets beyond the one-shot kernel's reach (CNN policies) stay on the process group's all-reduce either way."""
+    v = os.environ.get("AURPPO_DP_ALLREDUCE", "rccl").strip().lower()
+    if v not in ("rccl", "p2p"):
+        raise ValueError(f"AURPPO_DP_ALLREDUCE={v!r}: expected 'rccl' or 'p2p'")
+    return v
+
+
+def make_p2p_exchange(ops, max_floats, device):
+    """A ``P2PExchange`` over the default process group's ranks: the IPC handles travel through one ``all_gather_object`` at
+    set-up (whatever the group's backend is); nothing after that touches ``torch.distributed``."""
+    def exchange(mine):
+        if world_size() == 1:
+            return [mine]
+        out = [None] * world_size()
+        dist.all_gather_object(out, mine)
+        return out
+    return ops.P2PExchange(rank(), world_size(), max_floats, device, exchange)
+
+
 def collectives_capturable():
     """True when the default group's all-reduce can be recorded into a hipGraph: RCCL enqueues device work only;
     gloo stages through host memory and cannot be captured.  A process without a group has nothing to capture."""

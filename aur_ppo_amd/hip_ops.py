@@ -520,6 +520,80 @@ def mlp_ppo_apply(flat_param, flat_grad, exp_avg, exp_avg_sq, layout, lr_dev, st
     return out_norm
 
 
+def mlp_ppo_apply_parts(flat_param, flat_grad, exp_avg, exp_avg_sq, layout, lr_dev, step_dev, max_norm, betas, eps, out_norm,
+                        sq_part, rec=None, next_idx=None):
+    """``mlp_ppo_apply`` for a gradient that already is the mean over ranks and comes with partial sums of squares
+    (``P2PExchange.allreduce_mean_``): the clip's norm is their sum, nothing is rescaled."""
+    lib = _lib_or_raise()
+    n = layout["n_params"]
+    if min(flat_param.numel(), flat_grad.numel(), exp_avg.numel(), exp_avg_sq.numel()) < n:
+        raise ValueError("mlp_ppo_apply_parts: the flat bucket is smaller than the policy")
+    _wide_only_step(layout, "mlp_ppo_apply_parts")
+    ws = _workspace("mlp", lib.aurppo_mlp_workspace_bytes(n), flat_param.device)
+    lay = (C.c_int * 13)(*layout["offsets"])
+    _check(lib.aurppo_mlp_ppo_apply_parts_f32(
+        _ptr(flat_param), _ptr(flat_grad), _ptr(exp_avg), _ptr(exp_avg_sq), lay, n, layout["D"], _ptr(sq_part, torch.float64),
+        int(sq_part.numel()), float(max_norm), _ptr(lr_dev), _ptr(step_dev), float(betas[0]), float(betas[1]), float(eps),
+        _ptr(out_norm), _ptr(rec) if rec is not None else None, (rec.numel() // rec.shape[0]) if rec is not None else 4,
+        _ptr(next_idx, torch.int32) if next_idx is not None else None,
+        int(next_idx.numel()) if next_idx is not None else 0, C.c_void_p(ws.data_ptr()), _stream()), "aurppo_mlp_ppo_apply_parts_f32")
+    return out_norm
+
+
+class P2PExchange:
+    """One-shot all-reduce of a small flat gradient over peer memory (include/aurppo.h, csrc/p2p.hip): every rank publishes its
+    vector in a buffer the peers have mapped through HIP IPC and reads theirs directly -- one launch, one hop over xGMI, sums
+    formed in rank order (bit-identical on every rank).  ``exchange_handles`` is the one collective it needs, at set-up:
+    ``fn(bytes) -> [bytes of rank 0, bytes of rank 1, ...]`` (the trainer passes torch.distributed.all_gather_object)."""
+
+    def __init__(self, rank, world, max_floats, device, exchange_handles):
+        lib = _lib_or_raise()
+        if os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") != "0":
+            raise RuntimeError("P2PExchange: HSA_ENABLE_IPC_MODE_LEGACY=0 must be set before the process touches the GPU "
+                               "(this driver only supports dmabuf IPC)")
+        self.rank, self.world, self.n_cap, self.device = int(rank), int(world), int(max_floats), device
+        self._h = C.c_void_p()
+        with torch.cuda.device(device):
+            _check(lib.aurppo_p2p_create(C.byref(self._h), self.rank, self.world, self.n_cap, _stream()), "aurppo_p2p_create")
+            nb = lib.aurppo_p2p_handle_bytes()
+            mine = C.create_string_buffer(nb)
+            _check(lib.aurppo_p2p_get_handle(self._h, mine), "aurppo_p2p_get_handle")
+            every = exchange_handles(bytes(mine.raw))
+            if len(every) != self.world or any(len(h) != nb for h in every):
+                raise RuntimeError("P2PExchange: the handle exchange did not return one handle per rank")
+            if self.world > 1:
+                _check(lib.aurppo_p2p_open_peers(self._h, C.create_string_buffer(b"".join(every), nb * self.world)),
+                       "aurppo_p2p_open_peers")
+        self.sq_part = torch.zeros(lib.aurppo_p2p_parts(self.n_cap), dtype=torch.float64, device=device)
+
+    def allreduce_mean_(self, flat, n, step_dev, timeout_s=10.0):
+        """``flat[:n]`` <- mean over ranks; leaves the partial sums of squares of the result in ``self.parts(n)``."""
+        lib = _lib_or_raise()
+        _check(lib.aurppo_p2p_allreduce_mean_f32(self._h, _ptr(flat), int(n), _ptr(step_dev), _ptr(self.sq_part, torch.float64),
+                                                 float(timeout_s), _stream()), "aurppo_p2p_allreduce_mean_f32")
+        return flat
+
+    def parts(self, n):
+        return self.sq_part[:_lib_or_raise().aurppo_p2p_parts(int(n))]
+
+    def status(self):
+        """0 = every exchange met its peers; 1 + r = rank r's flag timed out at least once (sticky).  Synchronises the stream."""
+        v = C.c_int(0)
+        _check(_lib_or_raise().aurppo_p2p_status(self._h, C.byref(v), _stream()), "aurppo_p2p_status")
+        return int(v.value)
+
+    def close(self):
+        if self._h:
+            _lib_or_raise().aurppo_p2p_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def mlp_act(obs, noise, flat_param, layout, actions=None, logp=None, value=None):
     """K8: the rollout step of the MLP actor-critic in one launch.  ``noise``: (N,A) standard-normal draws
     (Gaussian head) or (N,) uniform draws (Categorical head); None -> value only.  Outputs may be rows of

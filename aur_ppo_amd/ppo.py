@@ -15,6 +15,7 @@ What differs from the reference on purpose (MI355X-first, results unchanged):
 """
 from __future__ import annotations
 
+import os
 import random
 import time
 
@@ -152,8 +153,18 @@ class ppo(FlatAdamMixin):
         # through the host and is not).  ``force_dp`` (test / rehearsal seam) takes the two-halves-around-the-all-reduce
         # path with a world of one, so a one-GPU box can rehearse the captured RCCL launch.
         self._dp = self.world > 1 or bool(params.get("force_dp", False))
+        # AURPPO_DP_ALLREDUCE=p2p: the default 64-64 policy's gradient goes through the one-shot exchange over HIP-IPC peer memory
+        # (csrc/p2p.hip) instead of the process group's all-reduce: nothing in the update then calls torch.distributed, so
+        # it is capturable whatever the group's backend is
+        self._p2p = None
+        if (self._dp and D.allreduce_choice() == "p2p" and self._mlp is not None and not self._mlp.get("wide")
+                and self._fused_adam and self._bucket_is_policy and hasattr(ops, "P2PExchange")):
+            self._p2p = D.make_p2p_exchange(ops, self._mlp["n_params"], self.device)
+        self._p2p_timeout = float(os.environ.get("AURPPO_P2P_TIMEOUT_S", "10"))      # a peer that never arrives raises p2p.status()
+        self.collective = ("p2p (one-shot exchange over HIP-IPC peer memory, csrc/p2p.hip)" if self._p2p is not None
+                           else (torch.distributed.get_backend() if self._dp and torch.distributed.is_initialized() else None))
         self.use_graph = (bool(params.get("hip_graph", True)) and self.device.type == "cuda"
-                          and (not self._dp or D.collectives_capturable()))
+                          and (not self._dp or self._p2p is not None or D.collectives_capturable()))
         self.graph_fallback = None  # why a captured update fell back to eager launches, if it did
         self._perm_events = None   # bench.py: [(start, end)] HIP events around each update's K2 work on the side stream
         self._rec = None           # (B,4) per-sample record written by K1
@@ -433,6 +444,17 @@ class ppo(FlatAdamMixin):
                     ops.mlp_ppo_grad(b_obs, k7_act, k7_rec, mb_inds, self.bucket.flat_param, self._mlp,
                                      self.bucket.flat_grad, self.clip_coeff, self.entropy_coeff, self.value_coeff,
                                      self.norm_adv, vmode, self._scalars[step], self._adam_t, chained=step > 0)
+                    if self._p2p is not None:
+                        # one launch, one hop: every rank reads its peers' published gradients and forms the mean in rank order
+                        n = self._mlp["n_params"]
+                        self._p2p.allreduce_mean_(self.bucket.flat_grad, n, self._adam_t, timeout_s=self._p2p_timeout)
+                        if step == 0 and self.first_grad_probe is not None:
+                            self.first_grad_probe.append(self.bucket.flat_grad.detach().clone())
+                        ops.mlp_ppo_apply_parts(self.bucket.flat_param, self.bucket.flat_grad, self._adam_m, self._adam_v, self._mlp,
+                                                self._lr_tensor, self._adam_t, self.max_grad_norm, g["betas"], g["eps"],
+                                                self._norms[step:step + 1], self._p2p.parts(n), rec=k7_rec, next_idx=nxt)
+                        step += 1
+                        continue
                     D.allreduce_sum_(self.bucket.flat_grad, self.world, force=True)
                     if step == 0 and self.first_grad_probe is not None:
                         self.first_grad_probe.append(self.bucket.flat_grad.detach().clone() / self.world)

@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--no-fused-mlp", action="store_true", help="per-op path (K3 + torch nets + K5) instead of K7")
     ap.add_argument("--shard-envs-per-gpu", type=int, default=512, help="second workload measured in the same process: BASELINE "
                     "config 4's per-GPU shard (0 = skip)")
+    ap.add_argument("--dp-allreduce", choices=["rccl", "p2p"], default=None, help="gradient exchange between ranks (sets "
+                    "AURPPO_DP_ALLREDUCE): the process group's all-reduce, or the one-shot exchange over HIP-IPC peer memory")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle comparison of the first (untimed) step")
     ap.add_argument("--force-dp", action="store_true", help="one rank, but the multi-GPU launch path: K7 grad -> RCCL "
                     "all-reduce (group of one) -> apply; rehearses the captured collective on a one-GPU box")
@@ -438,6 +440,8 @@ def oracle_full_update(args, hp, N, data, init_sd):
 
 def main():
     args = parse()
+    if args.dp_allreduce:
+        os.environ["AURPPO_DP_ALLREDUCE"] = args.dp_allreduce       # (before the ranks are spawned: they inherit it)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
     # stdout carries exactly ONE line, the JSON: anything a library prints there (RCCL announces its version on stdout when
@@ -622,7 +626,8 @@ def main():
                       "global_num_envs": N * world, "num_steps": T,
                       "parallelism": f"env-shard dp{world}" + (" (one rank through the RCCL launch path)" if args.force_dp else ""),
                       "rccl_ranks": torch.distributed.get_world_size() if dist_on else 1,
-                      "collective_backend": (torch.distributed.get_backend() if dist_on else None),
+                      "collective_backend": (getattr(agent, "collective", None) or (torch.distributed.get_backend() if dist_on else None)),
+                      "process_group_backend": (torch.distributed.get_backend() if dist_on else None),
                       "update_launch": launch_of(agent),
                       "minibatch_step": ("K3 + torch nets + K5" if agent._mlp is None else
                                          "K7w fused MLP step + K6b" if agent._mlp.get("wide") else

@@ -231,6 +231,37 @@ int aurppo_mlp_ppo_apply_f32(float* params, float* grads, float* exp_avg, float*
                              const float* rec, int rec_floats, const int32_t* next_idx, int next_M, void* workspace,
                              void* stream);
 
+/* aurppo_mlp_ppo_apply_f32 for a gradient that is already the mean over ranks (aurppo_p2p_allreduce_mean_f32 below) and comes
+ * with per-workgroup partial sums of squares: the clip's norm is their sum (n_part of them), nothing is rescaled. */
+int aurppo_mlp_ppo_apply_parts_f32(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const int* layout_h,
+                                   int n_params, int D, const double* sq_part, int n_part, double max_norm,
+                                   const float* lr_dev, const float* step_dev, double beta1, double beta2, double eps,
+                                   float* out_norm, const float* rec, int rec_floats, const int32_t* next_idx, int next_M,
+                                   void* workspace, void* stream);
+
+/* ---- one-shot gradient all-reduce over peer memory (one process per GPU; SURVEY 8e plan B) ------------------
+ * Where it sits in the reference: between loss.backward() and clip_grad_norm_ (src/ppo.py:266-268); upstream is
+ * single-process, so there is no call to cite -- the semantics are "mean of the ranks' gradients, identical bits on
+ * every rank".  An aurppo_p2p handle owns one exchange buffer (two slots of max_floats + flags) on the CURRENT device.
+ * Set-up, once, host side:  create on every rank -> get_handle (aurppo_p2p_handle_bytes() bytes) -> exchange the handles
+ * between the processes by any means (the trainer uses torch.distributed.all_gather_object) -> open_peers(handles of all
+ * ranks, in rank order; the own entry is ignored).  HSA_ENABLE_IPC_MODE_LEGACY=0 must be in every rank's environment.
+ * aurppo_p2p_allreduce_mean_f32: grads[0..n) <- mean over ranks, summed in rank order (bit-identical everywhere), in ONE
+ * launch and one hop over xGMI; sq_part (optional, aurppo_p2p_parts(n) doubles) receives per-workgroup partial sums of
+ * squares of the result.  step_dev: a device float holding the exchange's sequence number -- Adam's step count -- which
+ * every rank must advance identically by exactly one between calls (aurppo_mlp_ppo_grad_f32 does).  Capturable into a
+ * hipGraph.  A peer that does not arrive within timeout_s (<= 0: 10 s) raises a sticky status instead of hanging.      */
+typedef struct aurppo_p2p aurppo_p2p;
+int aurppo_p2p_handle_bytes(void);
+int aurppo_p2p_parts(int n);
+int aurppo_p2p_create(aurppo_p2p** out, int rank, int world, int max_floats, void* stream);
+int aurppo_p2p_get_handle(aurppo_p2p* x, void* handle_h);
+int aurppo_p2p_open_peers(aurppo_p2p* x, const void* handles_h);
+int aurppo_p2p_allreduce_mean_f32(aurppo_p2p* x, float* grads, int n, const float* step_dev, double* sq_part,
+                                  double timeout_s, void* stream);
+int aurppo_p2p_status(aurppo_p2p* x, int* status_h, void* stream); /* 0 ok; 1 + r: rank r's flag timed out (sticky) */
+int aurppo_p2p_destroy(aurppo_p2p* x);
+
 /* ---- K8: rollout step for the MLP actor-critic -----------------------------------------------------
  * Replaces `action, logprob, _, value = policy.evaluate(next_obs)` under no_grad and the three buffer row
  * stores that follow it (src/ppo.py:104-108), and with noise == NULL the bootstrap `policy.value(next_obs)`

@@ -117,6 +117,75 @@ def test_two_ranks_on_the_hip_path(tmp_path, over):
     torch.testing.assert_close(a0.bucket.flat_param.cpu(), r0["p1"], rtol=1e-6, atol=1e-7)
 
 
+# ---------------------------------------------------------------------------------- one-shot exchange over HIP-IPC peer memory
+def _p2p_worker(rank, world, port, out_dir, use_graph):
+    """AURPPO_DP_ALLREDUCE=p2p: the gradient exchange is csrc/p2p.hip's one-launch all-reduce over buffers the ranks map through
+    HIP IPC (same-device handles work, so two ranks on cuda:0 exercise the real protocol: publish, ticket, flag, poll, rank-ordered
+    sum).  The gloo group only carries the IPC handles and the initial broadcast."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      AURPPO_DP_ALLREDUCE="p2p", AURPPO_P2P_TIMEOUT_S="20")
+    assert os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") == "0", "the IPC mode must be in the environment before HIP starts"
+    from aur_ppo_amd import dist as D
+    from aur_ppo_amd.ppo import ppo
+    D.init_from_env(backend="gloo")
+    torch.manual_seed(50 + rank)
+    agent = ppo(_params(64, hip_graph=use_graph, total_timesteps=16 * 64 * 4))
+    assert agent._p2p is not None and agent.num_envs == 32 and agent.use_graph == use_graph and "p2p" in agent.collective
+    p0 = agent.bucket.flat_param.clone().cpu()
+    sc = _run(agent, _rollout(16, 64), agent.env_lo, agent.env_lo + 32, updates=4)
+    status = agent._p2p.status()
+    torch.save(dict(p0=p0, p1=agent.bucket.flat_param.clone().cpu(), sc=sc, norms=agent._norms.clone().cpu(), status=status,
+                    captured=agent._graph is not None, fallback=agent.graph_fallback, grad=agent.bucket.flat_grad.clone().cpu()),
+               os.path.join(out_dir, f"p{rank}_{int(use_graph)}.pt"))
+    D.barrier()
+    agent._p2p.close()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_ranks_exchange_gradients_over_ipc_peer_memory(tmp_path, monkeypatch):
+    """SURVEY 8e's plan B on the real HIP path: 4 updates x 8 optimizer steps of {K7 grad, one-shot exchange, clip + Adam}, eagerly and
+    as one hipGraph per update.  Every rank must end on the same bits (the sum is formed in rank order everywhere), no flag may
+    time out, and the run must end where the gloo all-reduce of test_two_ranks_on_the_hip_path ends (the same mean gradient; the
+    clip's norm is summed in a different order, hence 1e-6 instead of equality)."""
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for use_graph in (False, True):
+        mp.start_processes(_p2p_worker, args=(2, _free_port(), str(tmp_path), use_graph), nprocs=2, join=True, start_method="spawn")
+    e0, e1 = (torch.load(tmp_path / f"p{k}_0.pt") for k in range(2))
+    g0, g1 = (torch.load(tmp_path / f"p{k}_1.pt") for k in range(2))
+    for a, b in ((e0, e1), (g0, g1)):
+        assert a["status"] == 0 and b["status"] == 0, (a["status"], b["status"])
+        assert torch.equal(a["p0"], b["p0"])
+        assert torch.equal(a["p1"], b["p1"]) and torch.equal(a["norms"], b["norms"]) and torch.equal(a["grad"], b["grad"])
+        assert not torch.equal(a["sc"], b["sc"])                  # per-shard losses
+    assert g0["captured"] and g1["captured"], (g0["fallback"], g1["fallback"])
+    assert not e0["captured"]
+    torch.testing.assert_close(g0["sc"], e0["sc"], rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(g0["p1"], e0["p1"], rtol=1e-6, atol=1e-8)
+    # the same run through the process group's all-reduce (gloo here, RCCL on a multi-GPU node)
+    port = _free_port()
+    mp.start_processes(_worker_updates, args=(2, port, str(tmp_path), 4), nprocs=2, join=True, start_method="spawn")
+    r0 = torch.load(tmp_path / "r0.pt")
+    assert torch.equal(r0["p0"], e0["p0"])
+    torch.testing.assert_close(e0["sc"], r0["sc"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(e0["p1"], r0["p1"], rtol=1e-6, atol=1e-7)
+
+
+def _worker_updates(rank, world, port, out_dir, updates):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    os.environ.pop("AURPPO_DP_ALLREDUCE", None)
+    from aur_ppo_amd import dist as D
+    from aur_ppo_amd.ppo import ppo
+    D.init_from_env(backend="gloo")
+    torch.manual_seed(50 + rank)
+    agent = ppo(_params(64, total_timesteps=16 * 64 * 4))
+    assert agent._p2p is None
+    p0 = agent.bucket.flat_param.clone().cpu()
+    sc = _run(agent, _rollout(16, 64), agent.env_lo, agent.env_lo + 32, updates=updates)
+    torch.save(dict(p0=p0, p1=agent.bucket.flat_param.clone().cpu(), sc=sc), os.path.join(out_dir, f"r{rank}.pt"))
+    D.barrier()
+    torch.distributed.destroy_process_group()
+
+
 # ---------------------------------------------------------------------------------- RCCL: the captured collective
 def _rccl_worker(rank, world, port, out_dir, force_dp, use_graph, over=None):
     """One process per device over backend "nccl" (= RCCL).  world == 1 + force_dp: the multi-GPU launch path (K7 grad ->
