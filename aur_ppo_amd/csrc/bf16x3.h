@@ -48,6 +48,11 @@ __device__ __forceinline__ float bf_hi(unsigned p) { return __uint_as_float(p & 
 // (a, b) -> three packed pairs {plane k of a in the low half, of b in the high half}
 __device__ __forceinline__ void split3(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
     p0 = pack_bf16(a, b);
+#ifdef K7_EXP_CHEAP_SPLIT    // timing experiment (WRONG results; tools/k7_experiments.sh): 3 of the split's 11 vector instructions
+    p1 = p0;
+    p2 = p0;
+    return;
+#endif
     const float ra = a - bf_lo(p0), rb = b - bf_hi(p0);
     p1 = pack_bf16(ra, rb);
     p2 = pack_bf16(ra - bf_lo(p1), rb - bf_hi(p1));
@@ -165,9 +170,11 @@ __device__ __forceinline__ Frag3 plain_cols(const char* img, int rowb, int plane
 
 // ---- the six products
 __device__ __forceinline__ f32x16v mma32x3(const Frag3& a, const Frag3& b, f32x16v c) {
+#ifndef K7_EXP_HALF_MFMA     // timing experiment (WRONG results; tools/k7_experiments.sh): three of the six products
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], b.p[2], c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[2], b.p[0], c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[1], b.p[1], c, 0, 0, 0);
+#endif
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], b.p[1], c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[1], b.p[0], c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], b.p[0], c, 0, 0, 0);
