@@ -39,7 +39,10 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (same table: ~2.5 PF; nev
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--workload", choices=["mlp", "robot3", "robot5"], default="mlp", help="mlp (default): BASELINE's headline "
+                    "metric / config (4096 envs, T 128, MLP policy); robot3 / robot5: robot_ppo's GAE + update on image observations at "
+                    "BASELINE config 3's shape (256 envs, T 128, (1,128,128)) / config 5's per-GPU shard (256 envs, T 64, (3,84,84))")
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 100; 10 for the robot workloads)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--num-steps", type=int, default=128)
@@ -62,7 +65,10 @@ def parse():
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle comparison of the first (untimed) step")
     ap.add_argument("--force-dp", action="store_true", help="one rank, but the multi-GPU launch path: K7 grad -> RCCL "
                     "all-reduce (group of one) -> apply; rehearses the captured collective on a one-GPU box")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 100 if args.workload == "mlp" else 10
+    return args
 
 
 class EventProbe:
@@ -427,6 +433,117 @@ def run_workload(args, rank, world, dev, envs_per_gpu, steps, warmup, with_probe
                 mlp_events=mlp_events, side=side, perm_events=perm_events, every=every)
 
 
+def robot_small_sample(args, C, S):
+    """Parity gate + CPU baseline of the robot workloads on a BOUNDED sample: one ``robot_ppo.update`` at T = 16 and N = 32 (config 3)
+    / 128 (config 5) envs (the run's E epochs x 4 minibatches) on the HIP path and through ``oracle.reference_robot_update`` (the
+    restatement of src/robot_ppo.py:329-408 on torch-CPU convolutions) from the same weights, data and shuffle seed; the oracle's
+    pass is the timed CPU baseline.  Optimizer step 1 runs on identical weights and is held to 1e-5: that is the parity statement.
+    From step 2 on Adam has turned every rounding-level gradient element into a +-lr step of either sign (tests/test_robot_gpu.py
+    has the derivation; there 4 steps stay within 2e-4), so two correct implementations drift apart: the later steps' loss, policy
+    loss, value loss and entropy are only held to a drift bound of 5e-3 (a wrong gradient shows up orders above that), and the
+    largest relative difference per scalar is reported."""
+    from aur_ppo_amd.robot_actor_critic import robot_actor_critic
+    from aur_ppo_amd.robot_ppo import robot_ppo
+    from aur_ppo_amd.robot_run import build_parser, params_from_args
+    from oracle import ppo_oracle as O
+    T, N, E = 16, (32 if S == 128 else 128), args.epochs
+    p = params_from_args(build_parser().parse_args([]))
+    p.update(gym_id="Synthetic-arm", num_envs=N, num_steps=T, total_timesteps=N * T * 2, num_update_epochs=E, num_minibatches=4,
+             do_pretraining=False, log=False, clip_vloss=True, entropy_coeff=0.01, obs_size=S, obs_channels=C)
+    torch.manual_seed(2)
+    agent = robot_ppo(p)
+    cpu = robot_actor_critic(torch.device("cpu"), False, obs_shape=(C, S, S))
+    cpu.load_state_dict({k: v.cpu() for k, v in agent.policy.state_dict().items()})
+    g = torch.Generator().manual_seed(9)
+    buf = dict(states=(torch.rand(T, N, generator=g) < 0.5).float(), observations=torch.rand(T, N, C, S, S, generator=g),
+               actions=0.3 * torch.randn(T, N, 5, generator=g), true_actions=torch.zeros(T, N, 5),
+               rewards=(torch.rand(T, N, generator=g) < 0.3).float(), terminals=(torch.rand(T, N, generator=g) < 0.1).float())
+    with torch.no_grad():
+        _, _, lp, _, v = cpu.evaluate(buf["states"].view(-1), buf["observations"].view(-1, C, S, S), buf["actions"].view(-1, 5))
+    buf["log_probs"] = lp.view(T, N) + 0.05 * torch.randn(T, N, generator=g)
+    buf["values"] = v.view(T, N).clone()
+    for k, t in buf.items():
+        getattr(agent.buffer, k).copy_(t)
+    next_state, next_obs = (torch.rand(N, generator=g) < 0.5).float(), torch.rand(N, C, S, S, generator=g)
+    next_done = torch.zeros(N)
+    agent.seed_all(1)
+    ret, adv = agent.advantages(next_state.cuda(), next_obs.cuda(), next_done.cuda(), agent.buffer, T)
+    agent.update(agent.buffer.flatten(ret, adv), E, agent.batch_size, agent.minibatch_size, [])
+    got = agent._last_scalars.copy()
+    threads = args.cpu_threads or usable_cores()
+    torch.set_num_threads(threads)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        nv = cpu.value(next_state, next_obs).flatten()
+    ret_o, adv_o = O.gae(buf["rewards"].numpy(), buf["values"].numpy(), buf["terminals"].numpy(), nv.numpy(), next_done.numpy(),
+                         0.99, 0.95, O.GAE_MODE_SKIP_LAST)
+    flat_cpu = (buf["states"].view(-1), buf["observations"].view(-1, C, S, S), buf["log_probs"].reshape(-1),
+                buf["actions"].view(-1, 5), torch.from_numpy(adv_o).reshape(-1), torch.from_numpy(ret_o).reshape(-1),
+                buf["values"].reshape(-1), buf["true_actions"].view(-1, 5))
+    opt = torch.optim.Adam(cpu.parameters(), lr=p["learning_rate"], eps=1e-5)
+    rows = O.reference_robot_update(cpu, opt, flat_cpu, p, np.random.RandomState(1), agent.minibatch_size)
+    cpu_s = time.perf_counter() - t0
+    adv_err = float(np.abs(adv.cpu().numpy() - adv_o).max())
+    s1 = np.abs(got[0, :6] - rows[0, :6]) - (1e-5 * np.abs(rows[0, :6]) + 1e-6)
+    later = np.abs(got[1:, :4] - rows[1:, :4]) - (5e-3 * np.abs(rows[1:, :4]) + 5e-4)
+    rel = (np.abs(got[1:, :6] - rows[1:, :6]) / (np.abs(rows[1:, :6]) + 1e-3)).max(axis=0)
+    parity = {"adv_max_abs_err": adv_err, "step1_scalars_max_excess_over_1e-5": float(s1.max()),
+              "later_steps_max_excess_over_drift_bound_5e-3": float(later.max()),
+              "later_steps_max_rel_diff_per_scalar[loss,pg,vl,ent,old_kl,kl]": [float(f"{x:.3g}") for x in rel],
+              "optimizer_steps": int(got.shape[0]), "ok": bool(adv_err <= 1e-5 and s1.max() <= 0 and later.max() <= 0)}
+    base = {"value": N * T / cpu_s, "unit": "env-steps/s", "cores": threads, "kind": "port",
+            "sample": f"oracle.reference_robot_update (src/robot_ppo.py:329-408 on torch-CPU convolutions) + skip-last GAE at N={N} envs, "
+                      f"T={T}, E={E}, 4 minibatches of {agent.minibatch_size}, obs ({C},{S},{S}): {cpu_s:.1f} s for {N * T} env-steps"}
+    del agent
+    torch.cuda.empty_cache()
+    return base, parity
+
+
+def main_robot(args, json_fd):
+    """``--workload robot3 | robot5``: robot_ppo's GAE + update (src/robot_ppo.py:224-244,329-408) on synthetic image rollouts
+    resident in HBM; one step = one whole update (E epochs x minibatches of the CNN actor-critic).  MIOpen compiles its kernels
+    on first use of a shape (minutes on a fresh box): all of that happens in the untimed warm-up."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_robot as BR
+    cfg = 3 if args.workload == "robot3" else 5
+    C, S = (1, 128) if cfg == 3 else (3, 84)
+    base = parity = None
+    if args.cpu_baseline_updates > 0 and not args.no_parity:
+        base, parity = robot_small_sample(args, C, S)
+        log(f"small-sample parity: {parity}")
+    res = BR.run(cfg, epochs=args.epochs, minibatches=args.minibatches, updates=args.steps, warmup=max(1, args.warmup),
+                 kernel_table=True)
+    res.pop("_agent", None)
+    kt = res.get("kernel_table") or {}
+    N, T = res["N"], res["T"]
+    ms = res["ms_per_update"]
+    flops = res["conv_flops_per_update"]
+    roofline = {"bound": "mfma",
+                "kernel": "MIOpen convolutions of the actor / critic encoders, in aggregate (Winograd forward + data gradients, "
+                          "implicit-GEMM weight gradients, its layout transposes); K9 / K10 (csrc/pool.hip) are HBM-bound and listed in `top`",
+                "achieved": kt.get("library_conv_tflops"), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(kt["library_conv_tflops"] / MFMA_F32_PEAK_TFLOPS, 4) if kt.get("library_conv_tflops") else None,
+                "traffic": None,
+                "algorithmic_conv_flops_per_update": flops,
+                "whole_update_frac_of_fp32_mfma_peak": res["frac_of_fp32_mfma_peak"],
+                "library_conv_share_of_gpu_time": kt.get("library_conv_share"), "top": kt.get("top"),
+                "how": "direct-convolution FLOPs of both encoders, forward + both gradients (tools/bench_robot.py::conv_flops), over the "
+                       "summed device time of the library's convolution kernels in one more steady-state update under torch.profiler in "
+                       "this process; fp32 MFMA peak: the library runs fp32 kernels (Winograd does fewer multiplies than it is credited)"}
+    out = {"metric": "env-steps/sec through GAE+PPO-update at num_envs=4096,T=128; 1/2/4/8 GPU",
+           "value": N * T / (ms * 1e-3), "unit": "env-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": max(1, args.warmup),
+           "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": res["workload"] + f" -- BASELINE config {cfg}" + (" (per-GPU shard of 2048 envs / 8 GPUs)" if cfg == 5 else "")
+                                  + ", plain-CNN robot_actor_critic, NOT the headline configuration",
+                      "policy": res["policy"], "minibatch_step": "K3 gather + K10 first block + MIOpen convolutions + K9 block tails + K5 loss + K6b"},
+           "roofline": roofline, "cpu_baseline": base, "parity_checked": bool(parity["ok"]) if parity else False,
+           "parity": parity if parity else "not run (--cpu-baseline-updates 0 / --no-parity)", "graph_fallback": None}
+    sys.stdout.flush()
+    os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if parity is not None and not parity["ok"]:
+        sys.exit("bench.py: the robot update's small-sample parity gate failed -- see \"parity\" in the line above")
+
+
 def oracle_full_update(args, hp, N, data, init_sd):
     """oracle.reference_update of one whole update on ``data`` from ``init_sd`` (the checker; CPU)."""
     from oracle import ppo_oracle as O
@@ -449,6 +566,11 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    if args.workload != "mlp":
+        if args.gpus != 1:
+            sys.exit("bench.py: the robot workloads are single-GPU lines (config 5's per-GPU shard at N = 1)")
+        torch.cuda.set_device(0)
+        return main_robot(args, json_fd)
     from aur_ppo_amd import dist as D
     # AURPPO_BENCH_REHEARSE=1: every rank on cuda:0 over gloo -- a rehearsal of the N > 1 code path on a one-GPU box
     # (its timings mean nothing); the driver's runs use one device per rank over RCCL

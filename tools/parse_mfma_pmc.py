@@ -16,6 +16,7 @@ import re
 import sys
 
 kern, expect, out = sys.argv[1], float(sys.argv[2]), sys.argv[3]
+kerns = kern.split("|")            # several substrings: "a|b"
 N_SIMD, PEAK_HZ = 1024, 2.4e9
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
 durs = collections.defaultdict(list)
@@ -23,19 +24,19 @@ durs = collections.defaultdict(list)
 
 def key_of(name, grid):
     m = re.search(r"(k_\w+(?:<[^>]*>)?)", name)
-    return (m.group(1) if m else name[:60]) + f" grid={grid}"
+    return (m.group(1) if m else name.split("(")[0][:110]) + f" grid={grid}"
 
 
 for d in sys.argv[4:]:
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if kern in r["Kernel_Name"]:
+            if any(kq in r["Kernel_Name"] for kq in kerns):
                 vals[key_of(r["Kernel_Name"], r.get("Grid_Size", "?"))][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
         if not d.rstrip("/").endswith("a"):
             continue                       # durations from the pass that carries the MFMA counter
         for r in csv.DictReader(open(f)):
-            if kern in r["Kernel_Name"]:
+            if any(kq in r["Kernel_Name"] for kq in kerns):
                 durs[key_of(r["Kernel_Name"], r.get("Grid_Size", r.get("Grid_Size_X", "?")))].append(
                     (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9)
 res = {}
