@@ -24,6 +24,7 @@ int env_int(const char* name, int dflt) {
 AurppoKnobs parse_knobs() {
     AurppoKnobs k;
     k.k7_variant = env_int("AURPPO_K7_VARIANT", 3) == 2 ? 2 : 3;   // normalised HERE, once: 2 = k_mlp_step2, anything else = the default k_mlp_step3
+    k.k7w_variant = env_int("AURPPO_K7W_VARIANT", 3) == 2 ? 2 : 3;
     k.k7_spare_cus = env_int("AURPPO_MLP_SPARE_CUS", 8);
     k.static_tiles = env_int("AURPPO_STATIC_TILES", 0);
     k.k2_one_stream = env_int("AURPPO_K2_ONE_STREAM", 0);

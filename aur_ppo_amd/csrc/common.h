@@ -49,6 +49,7 @@ static inline int aurppo_device_slot() {
 // them.  None of them changes results beyond summation order; the defaults are the product configuration.
 struct AurppoKnobs {
     int k7_variant;        // AURPPO_K7_VARIANT: 3 (default) = 3 x bf16-split MFMA k_mlp_step3 (mlp3.hip), 2 = f32 MFMA k_mlp_step2; always one of the two (api.hip normalises)
+    int k7w_variant;       // AURPPO_K7W_VARIANT: 3 (default) = k_mlpw3_step (bf16x3 MFMA) for the shapes wider than 64, 2 = the fp32-MFMA k_mlpw_step
     int k7_spare_cus;      // AURPPO_MLP_SPARE_CUS: CUs K7 / K7w leave to the side stream's shuffle kernels (default 8)
     int static_tiles;      // AURPPO_STATIC_TILES=1: K7 / K7w deal tiles by static stride instead of through the counter, which
                            // fixes the order of every sum (bit-reproducible gradients; tests/test_determinism.py)

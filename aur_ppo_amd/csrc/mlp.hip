@@ -334,6 +334,21 @@ __device__ __forceinline__ void refresh_operand_copies(const OperandCopies& oc, 
                 if (e < 0 || e >= wc.Hd * in_dim) continue;
                 const int row = e / in_dim, col = e - row * in_dim;
                 const int nl = n * 3 + l;
+                if (wc.wop3) {
+                    // k_mlpw3_step's copies (mlp_wide.hip, w3::wop_index): slot (net, layer, direction) x column block x k-step x
+                    // plane x lane x 8; forward B[k][n = out] = W[out][k], backward (layers >= 1) B[k = out][n = in] = W[out][in]
+                    unsigned p0, p1, p2;
+                    bf3::split3(pn, 0.0f, p0, p1, p2);
+                    for (int dir = 0; dir < (l > 0 ? 2 : 1); ++dir) {
+                        const int nn = dir == 0 ? row : col, kk = dir == 0 ? col : row;
+                        const int at = (nl * 2 + dir) * (4 * 8 * 3 * 512) + (nn >> 5) * (8 * 3 * 512) +
+                                       (((kk >> 4) * 3) * 64 + (nn & 31) + 32 * ((kk >> 3) & 1)) * 8 + (kk & 7);
+                        wc.wop3[at] = (unsigned short)p0;
+                        wc.wop3[at + 512] = (unsigned short)p1;
+                        wc.wop3[at + 1024] = (unsigned short)p2;
+                    }
+                    continue;
+                }
                 {
                     const int blk = (row >> 5) * 4 + (col >> 5), lane = (row & 31) + 32 * (col & 1), m = (col & 31) >> 1;
                     wc.wop[(((nl * 2 + 0) * 16 + blk) * 64 + lane) * 16 + m] = pn;

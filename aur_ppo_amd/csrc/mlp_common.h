@@ -208,6 +208,7 @@ struct WideCopies {
     int w[2][3];       // float offsets of the hidden layers' weights in the bucket
     int NL, Hd, D;
     float* wop;
+    unsigned short* wop3;   // != nullptr: k_mlpw3_step's bf16-plane copies are the ones to refresh (mlp_wide.hip: w3::wop_index)
 };
 // next_idx != nullptr: the launch also forms the next minibatch's advantage partial sums (stats: (kStatBlocks, 2) doubles).
 int launch_adam_tail(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int n_params, const double* sq_part,

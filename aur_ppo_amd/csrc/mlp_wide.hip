@@ -22,6 +22,7 @@
 #include <stdlib.h>
 
 #pragma clang fp contract(fast)
+#include "bf16x3.h"
 #include "mlp_common.h"
 
 using namespace aurppo_mlp;
@@ -49,6 +50,7 @@ struct WideArgs {
     const int32_t* idx;    // (M,)
     const float* params;
     const float* wop;      // operand-order copies (k_mlpw_prep)
+    const unsigned short* wop3;   // k_mlpw3_step: bf16 planes of the hidden layers in operand order (k_mlpw3_prep)
     float* slabs;          // (pairs, n_params)
     double* loss_part;     // (pairs, 8)
     const double* stats;   // (n_stat_blocks, 2)
@@ -631,6 +633,647 @@ __global__ __launch_bounds__(256, DUAL ? 2 : 1) void k_mlpw_step(const WideArgs 
     }
 }
 
+// =====================================================================================================================
+// k_mlpw3_step -- K7w on the bf16 matrix pipe (round 4): k_mlpw_step<NL, false>'s geometry (one net per workgroup, four
+// waves, wave w = the w-th 32-column block of every layer, weight gradients persistent in registers) with k_mlp_step3's
+// arithmetic and operand handling (bf16x3.h: every fp32 operand as three bf16 planes, six v_mfma_f32_32x32x16_bf16 per
+// K = 16, fp32 accumulate -- fp32-equivalent, tools/bf16x3_check.hip):
+//   * activations are LDS images of bf16 planes -- X as two 64-column X images side by side, H_l (later dZ_l, in place) as
+//     128-feature F images -- written straight from the accumulators by the tanh / dZ epilogues; a fragment is one
+//     ds_read_b128 or two ds_read_b64_tr_b16 where the fp32 kernel issued a ds_read_b32 per matrix instruction (rocprofv3:
+//     k_mlpw_step<3,false> kept the matrix pipe busy 48 % of its 862 us -- on fp32 instructions that cost 2.7x the cycles);
+//   * the weights stream from L2 as bf16 planes in B-operand order (k_mlpw3_prep; refreshed in place by the optimizer launch
+//     of a chained minibatch), a layer's whole slice (<= 8 k-steps x 3 planes = 96 registers) one phase ahead of its use --
+//     one wave per SIMD has the 512-register budget for it next to the 12 x 16 accumulator registers;
+//   * head, loss lanes, column sums and the tile queue are k_mlpw_step's; the head gradients also go out as a bf16-plane
+//     image ([a 16][s 32]) for the two products that consume them.
+// Same arguments, slabs and loss partials as k_mlpw_step: k_mlp_reduce and the optimizer launch do not know the difference.
+namespace w3 {
+using namespace bf3;
+constexpr int kFPlaneW = HPW * kFRow;            // F image of 128 features: bytes per plane
+constexpr int kXHalf = 3 * kXPlane;              // one 64-column X image (three planes)
+constexpr int kW3RowW = 2 * HPW, kW3PlaneW = AP * kW3RowW;       // W3 image [a 16][i 128]
+constexpr int kDoRowW = 64, kDoPlaneW = AP * kDoRowW;            // dOut image [a 16][s 32]
+constexpr int kWopKs = 8;                        // k-steps of a weight slice (128 / 16)
+constexpr int kWopSlice = kWopKs * 3 * 512;      // bf16 elements of one (slot, column block) slice
+constexpr int kWopSlot = 4 * kWopSlice;          // one (net, layer, direction)
+constexpr int kWopElems = 2 * MAXL * 2 * kWopSlot;
+__device__ __host__ __forceinline__ int wop_slot(int net, int l, int dir) { return (net * MAXL + l) * 2 + dir; }
+// element (slot, column block cb, k-step ks, plane p, lane, j)
+__device__ __host__ __forceinline__ int wop_index(int slot, int cb, int ks, int p, int lane, int j) {
+    return slot * kWopSlot + cb * kWopSlice + ((ks * 3 + p) * 64 + lane) * 8 + j;
+}
+
+// byte offsets of the workgroup's LDS
+constexpr int oX = 0;                                  // [2 halves][3 planes][4 KB]
+constexpr int oH = oX + 2 * kXHalf;                    // [MAXL][3 planes][8 KB]
+constexpr int oW3 = oH + MAXL * 3 * kFPlaneW;          // [3 planes][4 KB]
+constexpr int oDo = oW3 + 3 * kW3PlaneW;               // [3 planes][1 KB]
+constexpr int oOut = oDo + 3 * kDoPlaneW;              // float [R][LDO]
+constexpr int oAct = oOut + 4 * R * LDO;               // float [R][LDO]
+constexpr int oDls = oAct + 4 * R * LDO;               // float [R][LDO]
+constexpr int oB = oDls + 4 * R * LDO;                 // float [MAXL][HPW]
+constexpr int oB3 = oB + 4 * MAXL * HPW;               // float [AP]
+constexpr int oLs = oB3 + 4 * AP;                      // float [AP]
+constexpr int oIvar = oLs + 4 * AP;                    // float [AP]
+constexpr int oRec = oIvar + 4 * AP;                   // float4 [R]
+constexpr int oSrc = oRec + 16 * R;                    // int [R]
+constexpr int oIdx = oSrc + 4 * R;                     // int [2][R]
+constexpr int kBytes = oIdx + 4 * 2 * R;
+static_assert(oH % 16 == 0 && oW3 % 16 == 0 && oDo % 16 == 0 && oOut % 16 == 0 && oRec % 16 == 0, "16-byte alignment of the images");
+static_assert(kBytes <= 160 * 1024, "one workgroup per CU");
+
+template <int PL>
+__device__ __forceinline__ Frag3 f_rows_p(const char* img, int f0, int ks, int lane) {
+    const int o = foff(f0 + (lane & 31), 16 * ks + 8 * (lane >> 5));
+    Frag3 f;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) f.p[p] = lds_b128(img + p * PL + o);
+    return f;
+}
+template <int PL>
+__device__ __forceinline__ Frag3 f_cols_p(const char* img, int ks, int lane) {
+    const TrLane t = tr_lane32(lane);
+    const int f = 16 * ks + t.kq;
+    const int o0 = foff(f, t.m0), o1 = foff(f + 4, t.m0);
+    Frag3 r;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) r.p[p] = join_tr(lds_tr(img + p * PL + o0), lds_tr(img + p * PL + o1));
+    return r;
+}
+template <int PL>
+__device__ __forceinline__ Frag3 f_cols16_p(const char* img, int s0, int ks, int lane) {
+    const TrLane t = tr_lane16(lane);
+    const int f = 32 * ks + t.kq;
+    const int o0 = foff(f, s0 + t.m0), o1 = foff(f + 4, s0 + t.m0);
+    Frag3 r;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) r.p[p] = join_tr(lds_tr(img + p * PL + o0), lds_tr(img + p * PL + o1));
+    return r;
+}
+template <int PL>
+__device__ __forceinline__ Frag3 f_rows16_p(const char* img, int f0, int lane) {
+    const int o = foff(f0 + (lane & 15), 8 * (lane >> 4));
+    Frag3 f;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) f.p[p] = lds_b128(img + p * PL + o);
+    return f;
+}
+// tanh(acc + bias) of a 32x32 block into an F image, four values (one 8-byte store per plane) at a time
+template <int PL>
+__device__ __forceinline__ void tanh_store_p(char* img, int f0, const f32x16& acc, float bias, int lane) {
+    const int f = f0 + (lane & 31), h = lane >> 5;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+        unsigned a0, a1, a2, b0, b1, b2;
+        split3(tanh_fast(acc[4 * gq + 0] + bias), tanh_fast(acc[4 * gq + 1] + bias), a0, a1, a2);
+        split3(tanh_fast(acc[4 * gq + 2] + bias), tanh_fast(acc[4 * gq + 3] + bias), b0, b1, b2);
+        const int o = foff(f, 8 * gq + 4 * h);
+        *reinterpret_cast<u32x2*>(img + 0 * PL + o) = u32x2{a0, b0};
+        *reinterpret_cast<u32x2*>(img + 1 * PL + o) = u32x2{a1, b1};
+        *reinterpret_cast<u32x2*>(img + 2 * PL + o) = u32x2{a2, b2};
+    }
+}
+// dZ = dH * (1 - h^2) over the block of h that sits in the image, written back in its place; returns the lane's column sum
+template <int PL>
+__device__ __forceinline__ float dz_in_place_p(char* img, int f0, const f32x16& dh, int lane) {
+    const int f = f0 + (lane & 31), h = lane >> 5;
+    float colsum = 0.0f;
+    u32x2 q[4][3];
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+        const int o = foff(f, 8 * gq + 4 * h);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) q[gq][p] = *reinterpret_cast<const u32x2*>(img + p * PL + o);
+    }
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+        const float h0 = join_lo(q[gq][0].x, q[gq][1].x, q[gq][2].x), h1 = join_hi(q[gq][0].x, q[gq][1].x, q[gq][2].x);
+        const float h2 = join_lo(q[gq][0].y, q[gq][1].y, q[gq][2].y), h3 = join_hi(q[gq][0].y, q[gq][1].y, q[gq][2].y);
+        const float d0 = dh[4 * gq + 0] * (1.0f - h0 * h0), d1 = dh[4 * gq + 1] * (1.0f - h1 * h1);
+        const float d2 = dh[4 * gq + 2] * (1.0f - h2 * h2), d3 = dh[4 * gq + 3] * (1.0f - h3 * h3);
+        colsum += (d0 + d1) + (d2 + d3);
+        unsigned a0, a1, a2, b0, b1, b2;
+        split3(d0, d1, a0, a1, a2);
+        split3(d2, d3, b0, b1, b2);
+        const int o = foff(f, 8 * gq + 4 * h);
+        *reinterpret_cast<u32x2*>(img + 0 * PL + o) = u32x2{a0, b0};
+        *reinterpret_cast<u32x2*>(img + 1 * PL + o) = u32x2{a1, b1};
+        *reinterpret_cast<u32x2*>(img + 2 * PL + o) = u32x2{a2, b2};
+    }
+    return colsum;
+}
+}  // namespace w3
+
+// wop3 = the bf16 planes of every hidden layer of both nets in operand order (w3::wop_index), written destination-first so
+// that the padding (rows >= Hd, columns >= the layer's input width) is zero without a clearing pass.  The first n_stat_blocks
+// workgroups form the advantage partial sums instead (as k_mlpw_prep).
+__global__ __launch_bounds__(256) void k_mlpw3_prep(const float* __restrict__ params, WideLayout L, int NL, int D, int Hd,
+                                                    unsigned short* __restrict__ wop3, const float4* __restrict__ rec, int rec_stride,
+                                                    const int32_t* __restrict__ idx, int M, double (*__restrict__ stats)[2],
+                                                    int n_stat_blocks, unsigned* __restrict__ tile_counter) {
+    __shared__ double sc[2][4];
+    if (tile_counter && blockIdx.x == 0 && threadIdx.x < 2) tile_counter[threadIdx.x] = 0u;
+    if ((int)blockIdx.x < n_stat_blocks) {
+        double s = 0.0, q = 0.0;
+        adv_partial_sums(rec, rec_stride, idx, M, blockIdx.x * 256 + threadIdx.x, n_stat_blocks * 256, s, q);
+        const double bs = block_sum<4>(s, sc[0]);
+        const double bq = block_sum<4>(q, sc[1]);
+        if (threadIdx.x == 0) {
+            stats[blockIdx.x][0] = bs;
+            stats[blockIdx.x][1] = bq;
+        }
+        return;
+    }
+    const int b = blockIdx.x - n_stat_blocks, nb = gridDim.x - n_stat_blocks;
+    constexpr int per_slot = 4 * w3::kWopKs * 512;     // plane-0 elements of one slot
+    for (int e = b * 256 + threadIdx.x; e < 2 * MAXL * 2 * per_slot; e += nb * 256) {
+        const int j = e & 7, lane = (e >> 3) & 63, ks = (e >> 9) & 7, cb = (e >> 12) & 3, slot = e >> 14;
+        const int dir = slot & 1, nl = slot >> 1, n = nl / MAXL, l = nl - n * MAXL;
+        if (l >= NL || (dir == 1 && l == 0)) continue;
+        const int in_dim = l == 0 ? D : Hd;
+        const float* W = params + L.w[n][l];
+        const int k = 16 * ks + 8 * (lane >> 5) + j, c = cb * 32 + (lane & 31);
+        // forward: B[k][n = out c] = W[c][k]; backward: B[k = out][n = in c] = W[k][c]
+        const int row = dir == 0 ? c : k, col = dir == 0 ? k : c;
+        const float v = (row < Hd && col < in_dim) ? W[row * in_dim + col] : 0.0f;
+        unsigned p0, p1, p2;
+        bf3::split3(v, 0.0f, p0, p1, p2);
+        const int at = w3::wop_index(slot, cb, ks, 0, lane, j);
+        wop3[at] = (unsigned short)p0;
+        wop3[at + 512] = (unsigned short)p1;
+        wop3[at + 1024] = (unsigned short)p2;
+    }
+}
+
+template <int NL>
+__global__ __launch_bounds__(256, 1) void k_mlpw3_step(const WideArgs a) {
+    using namespace w3;
+    extern __shared__ __attribute__((aligned(16))) char ldsb[];
+    __shared__ double s_red[2][kThreads / kWave];
+    __shared__ float s_mean, s_std;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int net = (int)(blockIdx.x & 1), cb = w, pair = (int)(blockIdx.x >> 1);
+    const int D = a.D, A = a.A, Hd = a.Hd;
+    const int HB = (Hd + 31) >> 5, DB = (D + 31) >> 5;
+    const int nksD = (D + 15) >> 4, nksH = (Hd + 15) >> 4, nks2H = (Hd + 31) >> 5;
+    const int AW = a.continuous ? A : 1;
+    const int out_dim = net == 0 ? A : 1;
+
+    char* const sX = ldsb + oX;
+    char* const sW3 = ldsb + oW3;
+    char* const sDo = ldsb + oDo;
+    float* const sOut = reinterpret_cast<float*>(ldsb + oOut);
+    float* const sAct = reinterpret_cast<float*>(ldsb + oAct);
+    float* const sDls = reinterpret_cast<float*>(ldsb + oDls);
+    float* const sB = reinterpret_cast<float*>(ldsb + oB);
+    float* const sB3 = reinterpret_cast<float*>(ldsb + oB3);
+    float* const sLs = reinterpret_cast<float*>(ldsb + oLs);
+    float* const sIvar = reinterpret_cast<float*>(ldsb + oIvar);
+    float4* const sRec = reinterpret_cast<float4*>(ldsb + oRec);
+    int* const sSrc = reinterpret_cast<int*>(ldsb + oSrc);
+    int* const sIdx = reinterpret_cast<int*>(ldsb + oIdx);
+    auto sH = [&](int l) -> char* { return ldsb + oH + l * 3 * kFPlaneW; };
+
+    // ---- what stays in LDS for the whole launch: zeroed images, W3 image, biases, log-std
+    {
+        u32x4* z = reinterpret_cast<u32x4*>(ldsb);
+        const u32x4 zero = {0u, 0u, 0u, 0u};
+        for (int e = tid; e < oOut / 16; e += kThreads) z[e] = zero;          // X, H, W3 and dOut images
+        for (int e = tid; e < R * LDO; e += kThreads) sDls[e] = 0.0f;
+    }
+    __syncthreads();
+    for (int e = tid; e < AP * HPW; e += kThreads) {
+        const int o = e / HPW, i = e - o * HPW;
+        if (o < out_dim && i < Hd) store_plain1(sW3, kW3RowW, kW3PlaneW, o, i, a.params[a.L.w[net][NL] + o * Hd + i]);
+    }
+    for (int e = tid; e < NL * HPW; e += kThreads) {
+        const int l = e / HPW, c = e - l * HPW;
+        sB[e] = c < Hd ? a.params[a.L.b[net][l] + c] : 0.0f;
+    }
+    if (tid < AP) {
+        sB3[tid] = tid < out_dim ? a.params[a.L.b[net][NL] + tid] : 0.0f;
+        const float ls = (a.continuous && tid < A) ? a.params[a.L.logstd + tid] : 0.0f;
+        const float sd = expf(ls);
+        sLs[tid] = ls;
+        sIvar[tid] = 1.0f / (sd * sd);
+    }
+    {
+        double sm = 0.0, q = 0.0;
+        for (int b = tid; b < a.n_stat_blocks; b += kThreads) {
+            sm += a.stats[2 * b];
+            q += a.stats[2 * b + 1];
+        }
+        const double ts = block_sum<kThreads / kWave>(sm, s_red[0]);
+        const double tq = block_sum<kThreads / kWave>(q, s_red[1]);
+        if (tid == 0) {
+            const double m = ts / (double)a.h.M;
+            double var = (tq - ts * m) / (double)(a.h.M - 1);
+            if (var < 0.0) var = 0.0;
+            s_mean = (float)m;
+            s_std = (float)sqrt(var);
+        }
+    }
+    __syncthreads();
+    const float mean = s_mean, denom = s_std + 1e-8f;
+    const float invM = 1.0f / (float)a.h.M;
+    const float g_ent = -a.h.ent_coef * invM;
+
+    // persistent accumulators: dW_l blocks (out-block ob, in-block cb), the head's two 16x16 blocks, bias columns
+    f32x16 gW[NL][4];
+#pragma unroll
+    for (int l = 0; l < NL; ++l)
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) gW[l][ob] = zero16();
+    f32x4 gW3[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float gb[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) gb[l] = 0.0f;
+    double l_a = 0, l_b = 0, l_c = 0, l_d = 0, l_e = 0;
+    float g_b3c = 0.0f, g_head = 0.0f;
+
+    // ---- this wave's weight slices: a layer's slice (<= 8 k-steps x 3 planes of 16 B per lane) one phase ahead of its use
+    // (a wave-uniform base in scalar registers + the lane's 32-bit byte offset + an immediate per fragment; written as 64-bit
+    // vector addresses they are formed once, hoisted out of the tile loop and spilled -- every load then waits behind a scratch
+    // reload: k_mlp_step3's lesson)
+    const char* const wbase0 = reinterpret_cast<const char*>(a.wop3) + 2 * (size_t)(cb * kWopSlice);
+    const char* wbase = wbase0;
+    int lane16 = lane * 16;
+    // (in two halves: k-steps 0..3 are requested one phase ahead and stay live across the epilogue and the barrier in between;
+    // k-steps 4..7 are requested at the top of the phase that uses them, behind the first half's 24 matrix instructions -- held
+    // whole, the 96 registers of a slice pushed the kernel's vector registers into scratch)
+    bf16x8 wreg[3 * kWopKs];
+#ifdef K7W_EXP_NO_WLOAD
+    int n_loaded = 0, n_loaded_hi = 0;
+#endif
+    auto load_w = [&](int l, int dir, int nks) {          // first half
+#ifdef K7W_EXP_NO_WLOAD       // timing experiment (WRONG results): the weight slices are fetched once per launch
+        if (wbase != wbase0 + 0 || n_loaded++) return;
+#endif
+        const char* m = wbase + 2 * (size_t)(wop_slot(net, l, dir) * kWopSlot);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            if (ks < nks) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p) wreg[3 * ks + p] = *reinterpret_cast<const bf16x8*>(m + (ks * 3 + p) * 1024 + lane16);
+            }
+    };
+    auto load_w_hi = [&](int l, int dir, int nks) {       // second half
+#ifdef K7W_EXP_NO_WLOAD
+        if (n_loaded_hi++) return;
+#endif
+        const char* m = wbase + 2 * (size_t)(wop_slot(net, l, dir) * kWopSlot);
+#pragma unroll
+        for (int ks = 4; ks < kWopKs; ++ks)
+            if (ks < nks) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p) wreg[3 * ks + p] = *reinterpret_cast<const bf16x8*>(m + (ks * 3 + p) * 1024 + lane16);
+            }
+    };
+    auto wfrag = [&](int ks) {
+        Frag3 f;
+        f.p[0] = wreg[3 * ks + 0];
+        f.p[1] = wreg[3 * ks + 1];
+        f.p[2] = wreg[3 * ks + 2];
+        return f;
+    };
+
+    const int n_tiles = (a.h.M + R - 1) / R;
+    // staging: 32 chunk slots of 4 columns per row (128 state floats), four slots per thread
+    const bool vec4 = (D % 4 == 0) && ((reinterpret_cast<size_t>(a.obs) & 15) == 0);
+    float xr[16], ar[2];
+    float4 p_rec = make_float4(0.f, 0.f, 0.f, 0.f);
+    int p_src = -1, n_idx = -1;
+    auto load_idx = [&](int tile) -> int {
+        const int m = tile * R + tid;
+        return (tile < n_tiles && m < a.h.M) ? a.idx[m] : -1;
+    };
+    const float* const act_base = a.actions ? a.actions : reinterpret_cast<const float*>(a.rec) + 4;
+    const int act_stride = a.actions ? AW : 16;
+    auto prefetch = [&](const int* sidx) {
+        if (vec4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = tid + u * kThreads, r = e >> 5, c4 = (e & 31) * 4;
+                const int src = sidx[r];
+                const bool ok = src >= 0 && c4 < D;
+                const float4 v = *reinterpret_cast<const float4*>(a.obs + (ok ? (size_t)src * D + c4 : (size_t)0));
+                xr[4 * u + 0] = ok ? v.x : 0.0f; xr[4 * u + 1] = ok ? v.y : 0.0f;
+                xr[4 * u + 2] = ok ? v.z : 0.0f; xr[4 * u + 3] = ok ? v.w : 0.0f;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int e = tid + u * kThreads, r = e >> 7, c = e & 127;
+                const int src = sidx[r];
+                xr[u] = (src >= 0 && c < D) ? a.obs[(size_t)src * D + c] : 0.0f;
+            }
+        }
+        if (net == 0) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int e = tid + u * kThreads, r = e >> 4, c = e & 15;
+                const int sa = sidx[r];
+                ar[u] = (sa >= 0 && c < AW) ? act_base[(size_t)sa * act_stride + c] : 0.0f;
+            }
+        }
+        if (tid < R) {
+            p_src = sidx[tid];
+            if (p_src >= 0) p_rec = a.rec[(size_t)p_src * a.rec_stride];
+        }
+    };
+    __shared__ int s_tile[4];
+    unsigned* const ctr = a.tile_counter + net;
+    const bool stat = a.static_tiles != 0;
+    const int n_wg = (int)(gridDim.x >> 1);
+    if (tid == 0) {
+        if (stat) {
+            s_tile[0] = pair; s_tile[1] = pair + n_wg; s_tile[2] = pair + 2 * n_wg; s_tile[3] = pair + 3 * n_wg;
+        } else {
+            const int t0 = (int)atomicAdd(ctr, 4u);
+            s_tile[0] = t0; s_tile[1] = t0 + 1; s_tile[2] = t0 + 2; s_tile[3] = t0 + 3;
+        }
+    }
+    if (cb < HB) load_w(0, 0, nksD);                        // layer 1's slice for the first tile
+    __syncthreads();
+    if (tid < R) {
+        sIdx[tid] = load_idx(s_tile[0]);
+        sIdx[R + tid] = load_idx(s_tile[1]);
+    }
+    __syncthreads();
+    prefetch(sIdx);
+    if (tid < R) n_idx = load_idx(s_tile[2]);
+
+    for (int it = 0;; ++it) {
+        const int tile = s_tile[it & 3];
+        if (tile >= n_tiles) break;
+        const int tile3 = s_tile[(it + 3) & 3];
+        int ln = lane;
+        asm volatile("" : "+v"(ln));          // opaque per-tile copy: LDS addresses are re-derived inside the phases, not hoisted and spilled
+        {
+            int wz = 0;                        // ... and the weight base (an opaque zero keeps it a scalar pointer per tile)
+            asm volatile("" : "+s"(wz));
+            wbase = wbase0 + wz;
+            lane16 = ln * 16;
+        }
+        // ---- land the prefetched tile as bf16 planes
+        if (vec4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = tid + u * kThreads, r = e >> 5, c4 = (e & 31) * 4;
+                if (c4 < D) store_x4(sX + (c4 >> 6) * kXHalf, r, c4 & 63, xr[4 * u + 0], xr[4 * u + 1], xr[4 * u + 2], xr[4 * u + 3]);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int e = tid + u * kThreads, r = e >> 7, c = e & 127;
+                if (c < D) store_x1(sX + (c >> 6) * kXHalf, r, c & 63, xr[u]);
+            }
+        }
+        if (net == 0) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int e = tid + u * kThreads;
+                sAct[(e >> 4) * LDO + (e & 15)] = ar[u];
+            }
+        }
+        if (tid < R) {
+            sSrc[tid] = p_src;
+            sRec[tid] = p_rec;
+            sIdx[(it & 1) * R + tid] = n_idx;
+        }
+        __syncthreads();
+        prefetch(sIdx + ((it + 1) & 1) * R);      // the next tile's rows, behind this tile's math
+        if (tid < R) n_idx = load_idx(tile3);
+
+        // ---- forward: H_1 .. H_NL
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            if (cb < HB) {
+                f32x16 acc = zero16();
+                if (l == 0) {
+                    load_w_hi(0, 0, nksD);
+#pragma unroll
+                    for (int ks = 0; ks < kWopKs; ++ks) {
+                        if (ks < nksD) acc = mma32x3(x_rows(sX + (ks >> 2) * kXHalf, ks & 3, ln), wfrag(ks), acc);
+                        if (ks & 1) __builtin_amdgcn_sched_barrier(0);      // operand reads at most two k-steps ahead (registers)
+                    }
+                } else {
+                    load_w_hi(l, 0, nksH);
+#pragma unroll
+                    for (int ks = 0; ks < kWopKs; ++ks) {
+                        if (ks < nksH) acc = mma32x3(f_cols_p<kFPlaneW>(sH(l - 1), ks, ln), wfrag(ks), acc);
+                        if (ks & 1) __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // the slice used next: the following layer's forward copy, or (behind the last layer) the top layer's backward copy
+                if (l + 1 < NL) load_w(l + 1, 0, nksH);
+                else if (NL > 1) load_w(NL - 1, 1, nksH);
+                tanh_store_p<kFPlaneW>(sH(l), cb * 32, acc, sB[l * HPW + cb * 32 + (ln & 31)], ln);
+            }
+            __syncthreads();
+        }
+        if (cb < 2) {   // head: 16 rows per wave on 16x16x32
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                if (ks < nks2H)
+                    acc = mma16x3(f_cols16_p<kFPlaneW>(sH(NL - 1), 16 * cb, ks, ln),
+                                  plain_rows(sW3, kW3RowW, kW3PlaneW, ln & 15, 32 * ks + 8 * (ln >> 4)), acc);
+            const int col = ln & 15;
+            const float bias = sB3[col];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sOut[(cb * 16 + 4 * (ln >> 4) + e) * LDO + col] = acc[e] + bias;
+        }
+        __syncthreads();
+        int tile4 = 0;
+        if (tid == 0) tile4 = stat ? tile + 4 * n_wg : (int)atomicAdd(ctr, 1u);
+
+        // ---- loss lanes (one per row): this net's half of the PPO terms; head outputs become their gradients, fp32 (column
+        // sums) and as a bf16-plane image (the two products below)
+        if (tid < R) {
+            float* out = sOut + tid * LDO;
+            if (sSrc[tid] >= 0) {
+                const float4 rc = sRec[tid];
+                if (net == 1) {
+                    const PpoSample t = ppo_sample(rc.x, rc.x, rc.y, out[0], rc.w, rc.z, mean, denom, invM, a.h);
+                    l_a += t.vl;
+                    out[0] = t.g_v;
+                    g_b3c += t.g_v;
+                } else if (a.continuous) {
+                    const float* act = sAct + tid * LDO;
+                    float logp = 0.0f, ent = 0.0f;
+                    for (int k = 0; k < A; ++k) {
+                        const float ls = sLs[k];
+                        const float zk = act[k] - out[k];
+                        logp += (-(zk * zk) * (0.5f * sIvar[k]) - ls) - 0.9189385332046727f;
+                        ent += (0.5f + 0.9189385332046727f) + ls;
+                    }
+                    const PpoSample t = ppo_sample(logp, rc.x, rc.y, rc.w, rc.w, rc.z, mean, denom, invM, a.h);
+                    l_a += t.pg; l_b += ent; l_c += t.okl; l_d += t.kl; l_e += t.cf;
+                    for (int k = 0; k < A; ++k) {
+                        const float zk = act[k] - out[k];
+                        out[k] = t.g_logp * (zk * sIvar[k]);
+                        sDls[tid * LDO + k] = t.g_logp * (zk * zk * sIvar[k] - 1.0f) + g_ent;
+                    }
+                } else {
+                    const float* act = sAct + tid * LDO;
+                    float mx = out[0];
+                    for (int k = 1; k < A; ++k) mx = fmaxf(mx, out[k]);
+                    float se = 0.0f;
+                    for (int k = 0; k < A; ++k) se += expf(out[k] - mx);
+                    const float lse = mx + logf(se);
+                    const int ai = (int)act[0];
+                    float logp = 0.0f, ent = 0.0f;
+                    for (int k = 0; k < A; ++k) {
+                        const float lpk = out[k] - lse;
+                        ent -= expf(lpk) * lpk;
+                        if (k == ai) logp = lpk;
+                    }
+                    const PpoSample t = ppo_sample(logp, rc.x, rc.y, rc.w, rc.w, rc.z, mean, denom, invM, a.h);
+                    l_a += t.pg; l_b += ent; l_c += t.okl; l_d += t.kl; l_e += t.cf;
+                    for (int k = 0; k < A; ++k) {
+                        const float lpk = out[k] - lse;
+                        const float pk = expf(lpk);
+                        out[k] = t.g_logp * ((k == ai ? 1.0f : 0.0f) - pk) + g_ent * (-pk * (lpk + ent));
+                    }
+                }
+            } else {
+                for (int k = 0; k < AP; ++k) out[k] = sDls[tid * LDO + k] = 0.0f;
+            }
+            for (int k = 0; k < AP; ++k) store_plain1(sDo, kDoRowW, kDoPlaneW, k, tid, k < out_dim ? out[k] : 0.0f);
+        }
+        __syncthreads();
+
+        // ---- head backward: column sums (d b3, d logstd), dH_NL -> dZ_NL (in place), dW3
+        if (net == 0 && w == 3 && lane < 2 * AP) {
+            const float* src = lane < AP ? sOut + lane : sDls + (lane - AP);
+            float cs = 0.0f;
+#pragma unroll
+            for (int r = 0; r < R; ++r) cs += src[r * LDO];
+            g_head += cs;
+        }
+        if (cb < HB) {
+            char* const HL = sH(NL - 1);
+            f32x16 acc = zero16();
+            acc = mma32x3(plain_cols(sDo, kDoRowW, kDoPlaneW, 0, 0, ln), plain_cols(sW3, kW3RowW, kW3PlaneW, 0, cb * 32, ln), acc);
+            {
+                const Frag3 da = plain_rows(sDo, kDoRowW, kDoPlaneW, ln & 15, 8 * (ln >> 4));
+#pragma unroll
+                for (int q = 0; q < 2; ++q) gW3[q] = mma16x3(da, f_rows16_p<kFPlaneW>(HL, cb * 32 + 16 * q, ln), gW3[q]);
+            }
+            float colsum = dz_in_place_p<kFPlaneW>(HL, cb * 32, acc, ln);
+            colsum += __shfl_xor(colsum, 32, kWave);
+            gb[NL - 1] += colsum;
+        }
+        __syncthreads();
+        // ---- hidden layers, top down: dW_l, dH_{l-1} -> dZ_{l-1} (in place)
+#pragma unroll
+        for (int l = NL - 1; l >= 1; --l) {
+            if (cb < HB) {
+                const char* const dZ = sH(l);
+                char* const Hp = sH(l - 1);
+                load_w_hi(l, 1, nksH);                      // (behind the dW chains below)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const Frag3 hb = f_rows_p<kFPlaneW>(Hp, cb * 32, ks, ln);
+#pragma unroll
+                    for (int ob = 0; ob < 4; ++ob) {
+                        if (ob < HB) gW[l][ob] = mma32x3(f_rows_p<kFPlaneW>(dZ, ob * 32, ks, ln), hb, gW[l][ob]);
+                        if (ob & 1) __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                f32x16 acc = zero16();
+#pragma unroll
+                for (int ks = 0; ks < kWopKs; ++ks) {
+                    if (ks < nksH) acc = mma32x3(f_cols_p<kFPlaneW>(dZ, ks, ln), wfrag(ks), acc);
+                    if (ks & 1) __builtin_amdgcn_sched_barrier(0);
+                }
+                if (l - 1 >= 1) load_w(l - 1, 1, nksH);
+                else load_w(0, 0, nksD);                    // layer 1's forward slice for the next tile
+                float colsum = dz_in_place_p<kFPlaneW>(Hp, cb * 32, acc, ln);
+                colsum += __shfl_xor(colsum, 32, kWave);
+                gb[l - 1] += colsum;
+            }
+            __syncthreads();
+        }
+        // ---- dW_1: this wave's 32 state columns against every out-block
+        if (cb < DB) {
+            const char* const dZ = sH(0);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const Frag3 xb = x_cols(sX + (cb >> 1) * kXHalf, ks, (cb & 1) * 32, ln);
+#pragma unroll
+                for (int ob = 0; ob < 4; ++ob) {
+                    if (ob < HB) gW[0][ob] = mma32x3(f_rows_p<kFPlaneW>(dZ, ob * 32, ks, ln), xb, gW[0][ob]);
+                    if (ob & 1) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        if (tid == 0) s_tile[it & 3] = tile4;
+        __syncthreads();
+    }
+
+    // ---- this workgroup's half of the pair's slab
+    float* slab = a.slabs + (size_t)pair * a.L.n_params;
+    {
+        const int col = cb * 32 + (lane & 31);
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            const int in_dim = l == 0 ? D : Hd;
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob) {
+                if (ob < HB && col < in_dim) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int o = ob * 32 + acc_row(e, lane);
+                        if (o < Hd) slab[a.L.w[net][l] + o * in_dim + col] = gW[l][ob][e];
+                    }
+                }
+            }
+            if (lane < 32 && col < Hd) slab[a.L.b[net][l] + col] = gb[l];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {       // 16x16 accumulator layout: row = head output, col = hidden unit
+            const int o = 4 * (lane >> 4) + e, c = cb * 32 + (lane & 15);
+            if (o < out_dim && cb < HB) {
+                if (c < Hd) slab[a.L.w[net][NL] + o * Hd + c] = gW3[0][e];
+                if (c + 16 < Hd) slab[a.L.w[net][NL] + o * Hd + c + 16] = gW3[1][e];
+            }
+        }
+    }
+    if (net == 0 && w == 3) {
+        if (lane < A) slab[a.L.b[0][NL] + lane] = g_head;
+        if (a.continuous && lane >= AP && lane - AP < A) slab[a.L.logstd + lane - AP] = g_head;
+    }
+    if (cb == 0) {
+        float c = lane < R ? g_b3c : 0.0f;
+        double v5[5] = {l_a, l_b, l_c, l_d, l_e};
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) c += __shfl_down(c, off, kWave);
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            double x = lane < R ? v5[q] : 0.0;
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) x += __shfl_down(x, off, kWave);
+            v5[q] = x;
+        }
+        if (lane == 0) {
+            double* lp = a.loss_part + (size_t)pair * 8;
+            if (net == 0) {
+                lp[0] = v5[0]; lp[2] = v5[1]; lp[3] = v5[2]; lp[4] = v5[3]; lp[5] = v5[4];
+            } else {
+                slab[a.L.b[1][NL]] = c;
+                lp[1] = v5[0];
+                lp[6] = (double)mean;
+                lp[7] = (double)s_std;
+            }
+        }
+    }
+}
+
 // K8w: policy.evaluate(next_obs) under no_grad + the three buffer row stores (src/ppo.py:103-108), or value only
 // (noise == nullptr, src/ppo.py:161).  Workgroup = (row tile, net).
 template <int NL>
@@ -700,6 +1343,7 @@ struct WideWs {
     unsigned* tile_counter;   // [2] (+ padding to 64 B)
     float* slabs;        // (kMaxSlabs, n_params)
     double* sq_part;     // (ceil(n_params / 64)) clip partial sums left by k_mlp_reduce
+    unsigned short* wop3;   // k_mlpw3_step's bf16-plane operand copies (w3::kWopElems), behind everything else
 };
 // slabs a launch can write: two both-net workgroups per CU for the narrow shapes (small n_params), one pair per two CUs otherwise
 int wide_slab_cap(int hidden, int D) { return (hidden <= 64 && D <= 64) ? kMaxSlabs : kMaxGrid / 2; }
@@ -712,6 +1356,8 @@ WideWs wide_ws(void* workspace, int n_params, int slab_cap) {
     v.tile_counter = reinterpret_cast<unsigned*>(v.wop + kOpFloats);
     v.slabs = reinterpret_cast<float*>(v.tile_counter + 16);
     v.sq_part = reinterpret_cast<double*>(v.slabs + (((size_t)slab_cap * (size_t)n_params + 15) / 16) * 16);
+    v.wop3 = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(v.sq_part) +
+                                               ((sizeof(double) * (size_t)((n_params + 63) / 64) + 63) / 64) * 64);
     return v;
 }
 
@@ -757,7 +1403,8 @@ extern "C" size_t aurppo_mlp_wide_workspace_bytes(int n_params, int hidden, int 
     // instead of 207 MB at 3 x 128 over 128 state floats); n_params = 0: the operand copies alone, all K8w needs
     const size_t slabs = (size_t)wide_slab_cap(hidden, state_dim) * (size_t)(n_params > 0 ? n_params : 0);
     return sizeof(double) * (2 * kStatBlocks + 8 * kMaxSlabs) + sizeof(float) * (size_t)kOpFloats + 64 +
-           sizeof(float) * slabs + 64 + sizeof(double) * (size_t)((n_params + 63) / 64) + 64;
+           sizeof(float) * slabs + 64 + sizeof(double) * (size_t)((n_params + 63) / 64) + 128 +
+           sizeof(unsigned short) * (size_t)w3::kWopElems + 64;
 }
 
 namespace {
@@ -798,13 +1445,23 @@ static int wide_step_impl(const float* obs, const float* actions, const float* r
     a.h = make_hyper(M, clip, ent_coef, vf_coef, norm_adv, vloss_mode);
     const WideWs wv = wide_ws(workspace, n_params, wide_slab_cap(hidden, D));
     a.stats = wv.stats; a.loss_part = wv.loss_part; a.wop = wv.wop; a.slabs = wv.slabs; a.tile_counter = wv.tile_counter;
+    a.wop3 = wv.wop3;
     hipStream_t s = (hipStream_t)stream;
     int sb = (M + 1023) / 1024;
     if (sb > kStatBlocks) sb = kStatBlocks;
     a.n_stat_blocks = sb;
+    // layers and state at most two 32-column blocks wide: one workgroup carries both nets (k_mlpw_step<., true>, fp32 MFMA);
+    // anything wider: one net per workgroup on the bf16 pipe (k_mlpw3_step; AURPPO_K7W_VARIANT=2 keeps the fp32-MFMA k_mlpw_step)
+    const bool dual = hidden <= 64 && D <= 64;
+    const AurppoKnobs& knobs = aurppo_knobs();
+    const bool bf3k = !dual && knobs.k7w_variant == 3;
     if (!(tail && tail->chained)) {   // otherwise the previous chained call's optimizer launch has left all of this
-        hipLaunchKernelGGL(k_mlpw_prep, dim3(sb + 96), dim3(256), 0, s, params, a.L, num_layers, D, hidden, wv.wop, a.rec,
-                           a.rec_stride, idx, M, reinterpret_cast<double (*)[2]>(wv.stats), sb, wv.tile_counter);
+        if (bf3k)
+            hipLaunchKernelGGL(k_mlpw3_prep, dim3(sb + 96), dim3(256), 0, s, params, a.L, num_layers, D, hidden, wv.wop3, a.rec,
+                               a.rec_stride, idx, M, reinterpret_cast<double (*)[2]>(wv.stats), sb, wv.tile_counter);
+        else
+            hipLaunchKernelGGL(k_mlpw_prep, dim3(sb + 96), dim3(256), 0, s, params, a.L, num_layers, D, hidden, wv.wop, a.rec,
+                               a.rec_stride, idx, M, reinterpret_cast<double (*)[2]>(wv.stats), sb, wv.tile_counter);
         AURPPO_LAUNCH_CHECK("k_mlpw_prep");
     }
     static int cus_of[kMaxDevices] = {0};
@@ -815,20 +1472,24 @@ static int wide_step_impl(const float* obs, const float* actions, const float* r
         cus_of[dslot] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : kMaxGrid;
     }
     const int n_tiles = (M + R - 1) / R;
-    // layers and state at most two 32-column blocks wide: one workgroup carries both nets (k_mlpw_step<., true>)
-    const bool dual = hidden <= 64 && D <= 64;
     // 8 CUs left to the side stream's shuffle kernels, as K7; a both-net workgroup is built to share its CU with a second one
-    const AurppoKnobs& knobs = aurppo_knobs();
     a.static_tiles = knobs.static_tiles ? 1 : 0;
     const int spare = knobs.k7_spare_cus >= 0 ? knobs.k7_spare_cus : 8;
     int pairs = dual ? 2 * (cus_of[dslot] - spare) : (cus_of[dslot] - spare) / 2;
     if (pairs > (dual ? kMaxSlabs : kMaxGrid / 2)) pairs = dual ? kMaxSlabs : kMaxGrid / 2;
     if (pairs > n_tiles) pairs = n_tiles;
     if (pairs < 1) pairs = 1;
-    static bool attr[kMaxDevices][2][MAXL] = {};
+    static bool attr[kMaxDevices][3][MAXL] = {};
     if (ev_begin) AURPPO_HIP_TRY(hipEventRecord((hipEvent_t)ev_begin, s));
     const int grid = dual ? pairs : 2 * pairs;
-    bool* ad = &attr[dslot][dual ? 1 : 0][num_layers - 1];
+    bool* ad = &attr[dslot][bf3k ? 2 : (dual ? 1 : 0)][num_layers - 1];
+    if (bf3k) {
+        switch (num_layers) {
+            case 1: rc = launch_wide(k_mlpw3_step<1>, ad, grid, (size_t)w3::kBytes, s, a); break;
+            case 2: rc = launch_wide(k_mlpw3_step<2>, ad, grid, (size_t)w3::kBytes, s, a); break;
+            default: rc = launch_wide(k_mlpw3_step<3>, ad, grid, (size_t)w3::kBytes, s, a); break;
+        }
+    } else
     switch (num_layers * 2 + (dual ? 1 : 0)) {
         case 2: rc = launch_wide(k_mlpw_step<1, false>, ad, grid, wide_lds_bytes<false, 1>(1), s, a); break;
         case 3: rc = launch_wide(k_mlpw_step<1, true>, ad, grid, wide_lds_bytes<true, 1>(2), s, a); break;
@@ -850,6 +1511,7 @@ static int wide_step_impl(const float* obs, const float* actions, const float* r
     for (int n = 0; n < 2; ++n)
         for (int l = 0; l < 3; ++l) wc.w[n][l] = l < num_layers ? a.L.w[n][l] : n_params;
     wc.NL = num_layers; wc.Hd = hidden; wc.D = D; wc.wop = wv.wop;
+    wc.wop3 = bf3k ? wv.wop3 : nullptr;
     return launch_adam_tail(tail->params_rw, grads, tail->exp_avg, tail->exp_avg_sq, n_params, wv.sq_part, tail->max_norm,
                             tail->lr_dev, tail->step_dev, tail->beta1, tail->beta2, tail->eps, tail->out_norm, s,
                             tail->next_idx ? &wc : nullptr, a.rec, a.rec_stride, tail->next_idx, tail->next_M, wv.stats, bc);
