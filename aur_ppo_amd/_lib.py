@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(_HERE, "libaurppo_hip.so")
 
 # every symbol include/aurppo.h declares (tests/test_abi.py checks the header against this list)
 SYMBOLS = (
-    "aurppo_version", "aurppo_last_error", "aurppo_device_count", "aurppo_k7_variant", "aurppo_reload_knobs", "aurppo_gae_f32", "aurppo_gae_pack_f32",
+    "aurppo_version", "aurppo_last_error", "aurppo_device_count", "aurppo_k7_variant", "aurppo_reload_knobs", "aurppo_k7w_kernel", "aurppo_gae_f32", "aurppo_gae_pack_f32",
     "aurppo_mt19937_create", "aurppo_mt19937_destroy", "aurppo_mt19937_seed", "aurppo_mt19937_get_state",
     "aurppo_mt19937_set_state", "aurppo_mt19937_status_f32", "aurppo_arange_i32", "aurppo_shuffle_i32", "aurppo_shuffle_epochs_i32",
     "aurppo_gather_f32", "aurppo_loss_workspace_bytes", "aurppo_loss_fwd_bwd_f32", "aurppo_loss_fwd_bwd_packed_f32",
@@ -79,6 +79,7 @@ def load() -> C.CDLL:
     lib.aurppo_mlp_ppo_grad_f32.argtypes = [vp] * 4 + [i32] * 5 + [vp, C.POINTER(i32), i32, vp, f64, f64, f64, i32, i32, vp, vp, i32, vp, vp]
     lib.aurppo_mlp_ppo_apply_f32.argtypes = [vp] * 4 + [C.POINTER(i32), i32, i32, f64, f64, vp, vp, f64, f64, f64, vp, vp, i32, vp, i32, vp, vp]
     lib.aurppo_mlp_ppo_apply_parts_f32.argtypes = [vp] * 4 + [C.POINTER(i32), i32, i32, vp, i32, f64, vp, vp, f64, f64, f64, vp, vp, i32, vp, i32, vp, vp]
+    lib.aurppo_k7w_kernel.argtypes = [i32, i32]
     lib.aurppo_p2p_parts.argtypes = [i32]
     lib.aurppo_p2p_create.argtypes = [C.POINTER(vp), i32, i32, i32, vp]
     lib.aurppo_p2p_get_handle.argtypes = [vp, vp]

@@ -1407,6 +1407,14 @@ extern "C" size_t aurppo_mlp_wide_workspace_bytes(int n_params, int hidden, int 
            sizeof(unsigned short) * (size_t)w3::kWopElems + 64;
 }
 
+// Which kernel aurppo_mlp_wide_ppo_*_f32 launches for a net shape: 1 = k_mlpw_step<., true> (both nets per workgroup, fp32 MFMA:
+// nothing wider than 64), 2 = k_mlpw_step<., false> (one net per workgroup, fp32 MFMA), 3 = k_mlpw3_step (one net per workgroup,
+// bf16 MFMA over three-way splits -- the default for the wider shapes; AURPPO_K7W_VARIANT=2 selects 2).
+extern "C" int aurppo_k7w_kernel(int hidden, int state_dim) {
+    if (hidden <= 64 && state_dim <= 64) return 1;
+    return aurppo_knobs().k7w_variant == 3 ? 3 : 2;
+}
+
 namespace {
 struct WideTail {   // the optimizer half of aurppo_mlp_wide_ppo_minibatch_f32
     float* params_rw;

@@ -346,6 +346,16 @@ def mlp_step_flops(layout, M):
     return 2 * total * M
 
 
+def k7w_kernel(hidden, state_dim):
+    """Which K7w kernel runs for a net shape: 1 both nets per workgroup (fp32 MFMA), 2 one net (fp32 MFMA), 3 one net (bf16x3 MFMA)."""
+    return int(_lib_or_raise().aurppo_k7w_kernel(int(hidden), int(state_dim)))
+
+
+def k7w_kernel_name(hidden, state_dim, num_layers):
+    k = k7w_kernel(hidden, state_dim)
+    return {1: f"k_mlpw_step<{num_layers}, true>", 2: f"k_mlpw_step<{num_layers}, false>", 3: f"k_mlpw3_step<{num_layers}>"}[k]
+
+
 def reload_knobs():
     """Make the library re-read its AURPPO_* environment knobs now (it reads them once per process otherwise)."""
     _check(_lib_or_raise().aurppo_reload_knobs(), "aurppo_reload_knobs")

@@ -659,7 +659,7 @@ def main():
         ms = float(np.mean([b.elapsed_time(e) for b, e in mlp_events]))
         flops = H.mlp_step_flops(agent._mlp, M)
         ach = flops / (ms * 1e-3) / 1e12
-        kname = ("k_mlpw_step (K7w" if agent._mlp.get("wide") else ("k_mlp_step3" if k7_variant == 3 else "k_mlp_step2") + " (K7")
+        kname = (f"{H.k7w_kernel_name(args.hidden_dim, Dm, args.num_layers)} (K7w" if agent._mlp.get("wide") else ("k_mlp_step3" if k7_variant == 3 else "k_mlp_step2") + " (K7")
         roofline = {"bound": "mfma", "kernel": kname + ": gather + actor/critic forward + PPO loss + backward)",
                     "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
@@ -671,6 +671,15 @@ def main():
                     "how": f"hipEvent pair recorded inside the library around the K7 kernel, one extra stand-alone "
                            f"launch every {run['every']}th step on the update's own minibatch"
                            + (" (the update itself is a hipGraph)" if agent._graph is not None else "")}
+        wide_bf3 = bool(agent._mlp.get("wide")) and H.k7w_kernel(args.hidden_dim, Dm) == 3
+        if wide_bf3:
+            # k_mlpw3_step runs on the bf16 pipe too: priced the same way (6 x the algorithmic FLOPs against 2 500 TFLOP/s)
+            roofline["vs_fp32_mfma"] = {"achieved": roofline["achieved"], "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                        "frac": roofline["frac"],
+                                        "what": "the algorithmic fp32 FLOPs priced at the fp32 MFMA peak the kernel does NOT run on"}
+            ach6 = 6.0 * flops / (ms * 1e-3) / 1e12
+            roofline.update(achieved=round(ach6, 1), peak=MFMA_BF16_PEAK_TFLOPS, frac=round(ach6 / MFMA_BF16_PEAK_TFLOPS, 4),
+                            dtype_of_peak="bf16 MFMA dense (each fp32 product = 6 bf16 products, fp32 accumulate)")
         if k7_variant != 2 and not agent._mlp.get("wide"):
             # The kernel runs on the BF16 matrix pipe: six bf16 products per fp32 product.  The roof it is held to is that
             # pipe's (2.5 PFLOP/s dense): `achieved` = 6 x the algorithmic fp32 FLOPs / duration, `frac` against 2 500; the
@@ -741,7 +750,10 @@ def main():
            "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None,
-           "dtype": "f32 (3xbf16-split MFMA, fp32 accumulate)" if (fused and k7_variant == 3) else "f32", "data": "synthetic",
+           "dtype": ("f32 (3xbf16-split MFMA, fp32 accumulate)" if ((fused and k7_variant == 3) or
+                                                                       (agent._mlp is not None and agent._mlp.get("wide")
+                                                                        and H.k7w_kernel(args.hidden_dim, Dm) == 3)) else "f32"),
+           "data": "synthetic",
            "config": {"workload": f"synthetic continuous obs_dim={Dm} act_dim={A}, num_envs={N}/GPU x {world} GPU, "
                                   f"T={T}, E={args.epochs}, {args.minibatches} minibatches/epoch (M={M}), "
                                   f"{args.num_layers}x{args.hidden_dim} tanh MLP actor+critic, Adam, random-init weights",

@@ -74,6 +74,11 @@ int aurppo_k7_variant(void);
 /* The library reads its AURPPO_* environment knobs once per process; this re-reads them now (diagnostics: bench.py switches
  * AURPPO_K7_VARIANT after its timed region to time the fp32-MFMA build beside the default).  Returns 0. */
 int aurppo_reload_knobs(void);
+/* Which kernel the aurppo_mlp_wide_* entry points launch for a net shape (K7w): 1 = both nets per workgroup on fp32 MFMA
+ * (hidden_dim and state_dim <= 64), 2 = one net per workgroup on fp32 MFMA, 3 = one net per workgroup on bf16 MFMA over
+ * three-way splits (default for the wider shapes; AURPPO_K7W_VARIANT=2 selects 2).  Same results to the tolerances of
+ * tests/test_mlp_wide.py. */
+int aurppo_k7w_kernel(int hidden, int state_dim);
 
 /* ---- K1: advantage estimation -------------------------------------------------------------
  * Replaces ppo.run_gae / ppo.normal_advantage (src/ppo.py:125-157; duplicates in

@@ -74,7 +74,7 @@ def main():
         t_act = timed(lambda: H.mlp_act(o1, nz, bucket.flat_param, lay), 50)
         with torch.no_grad():
             t_act_t = timed(lambda: pol.evaluate(o1), 20)
-        rows.append(dict(hidden=hidden, layers=layers, D=D, kernel=f"K7 (k_mlp_step{H.k7_variant()})" if not lay["wide"] else "K7w (k_mlpw_step)",
+        rows.append(dict(hidden=hidden, layers=layers, D=D, kernel=f"K7 (k_mlp_step{H.k7_variant()})" if not lay["wide"] else f"K7w ({H.k7w_kernel_name(hidden, D, layers)})",
                          n_params=lay["n_params"], gflop=round(flops / 1e9, 2), main_kernel_us=round(sorted(ks)[2], 1),
                          step_us=round(t_f, 1), per_op_us=round(t_p, 1), speedup=round(t_p / t_f, 1),
                          frac_of_fp32_mfma_peak=round(flops / (sorted(ks)[2] * 1e-6) / PEAK, 3),
