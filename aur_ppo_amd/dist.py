@@ -94,7 +94,24 @@ def make_p2p_exchange(ops, max_floats, device):
         out = [None] * world_size()
         dist.all_gather_object(out, mine)
         return out
-    return ops.P2PExchange(rank(), world_size(), max_floats, device, exchange)
+    # A rank whose set-up fails (peer mapping refused, no IPC support) must not leave the others waiting in the next collective:
+    # every rank reports, and all of them raise together if any of them could not open its peers.
+    x, err = None, None
+    try:
+        x = ops.P2PExchange(rank(), world_size(), max_floats, device, exchange)
+    except Exception as e:       # noqa: BLE001 -- reported below, on every rank
+        err = f"rank {rank()}: {type(e).__name__}: {e}"
+    if world_size() > 1:
+        errs = [None] * world_size()
+        dist.all_gather_object(errs, err)
+        bad = [e for e in errs if e]
+        if bad:
+            if x is not None:
+                x.close()
+            raise RuntimeError("one-shot gradient exchange could not be set up: " + " | ".join(bad)[:600])
+    elif err:
+        raise RuntimeError(err)
+    return x
 
 
 def collectives_capturable():

@@ -564,13 +564,19 @@ class P2PExchange:
         self.rank, self.world, self.n_cap, self.device = int(rank), int(world), int(max_floats), device
         self._h = C.c_void_p()
         with torch.cuda.device(device):
-            _check(lib.aurppo_p2p_create(C.byref(self._h), self.rank, self.world, self.n_cap, _stream()), "aurppo_p2p_create")
             nb = lib.aurppo_p2p_handle_bytes()
-            mine = C.create_string_buffer(nb)
-            _check(lib.aurppo_p2p_get_handle(self._h, mine), "aurppo_p2p_get_handle")
-            every = exchange_handles(bytes(mine.raw))
+            mine, err = b"", None
+            try:        # a rank that cannot create its buffer still takes part in the handle exchange (with an empty handle):
+                _check(lib.aurppo_p2p_create(C.byref(self._h), self.rank, self.world, self.n_cap, _stream()), "aurppo_p2p_create")
+                buf = C.create_string_buffer(nb)
+                _check(lib.aurppo_p2p_get_handle(self._h, buf), "aurppo_p2p_get_handle")
+                mine = bytes(buf.raw)
+            except RuntimeError as e:
+                err = str(e)
+            every = exchange_handles(mine)          # ... so that every rank sees the failure and raises, none waits for ever
             if len(every) != self.world or any(len(h) != nb for h in every):
-                raise RuntimeError("P2PExchange: the handle exchange did not return one handle per rank")
+                raise RuntimeError("P2PExchange: not every rank could publish an exchange buffer"
+                                   + (f" (this rank: {err})" if err else ""))
             if self.world > 1:
                 _check(lib.aurppo_p2p_open_peers(self._h, C.create_string_buffer(b"".join(every), nb * self.world)),
                        "aurppo_p2p_open_peers")

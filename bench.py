@@ -62,6 +62,7 @@ def parse():
                     "config 4's per-GPU shard (0 = skip)")
     ap.add_argument("--dp-allreduce", choices=["rccl", "p2p"], default=None, help="gradient exchange between ranks (sets "
                     "AURPPO_DP_ALLREDUCE): the process group's all-reduce, or the one-shot exchange over HIP-IPC peer memory")
+    ap.add_argument("--one-exchange", action="store_true", help="at N > 1 do not measure the other gradient exchange as well")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle comparison of the first (untimed) step")
     ap.add_argument("--force-dp", action="store_true", help="one rank, but the multi-GPU launch path: K7 grad -> RCCL "
                     "all-reduce (group of one) -> apply; rehearses the captured collective on a one-GPU box")
@@ -591,6 +592,41 @@ def main():
     shard = None
     if args.shard_envs_per_gpu > 0 and args.shard_envs_per_gpu != args.envs_per_gpu:
         shard = run_workload(args, rank, world, dev, args.shard_envs_per_gpu, args.steps, args.warmup, False)
+    # One process per GPU: the same two workloads once more through the OTHER gradient exchange (RCCL's all-reduce <-> the one-shot
+    # exchange over HIP-IPC peer memory), in this same process -- so that a single multi-GPU run of the default command says what
+    # either costs.  `value` stays the primary arm's; this is the `other_exchange` object.  Every rank takes the same path (a
+    # set-up failure is agreed on across ranks before anybody raises, dist.make_p2p_exchange).
+    other = None
+    if (world > 1 or args.force_dp) and not args.one_exchange and args.num_layers == 2 and args.hidden_dim == 64 and not args.no_fused_mlp:
+        cur = D.allreduce_choice()
+        alt = "p2p" if cur == "rccl" else "rccl"
+        os.environ["AURPPO_DP_ALLREDUCE"] = alt
+        other = {"exchange": alt}
+        try:
+            o_main = run_workload(args, rank, world, dev, args.envs_per_gpu, args.steps, args.warmup, False)
+            other["collective_backend"] = getattr(o_main["agent"], "collective", None)
+            other["main"] = {"ms_per_step": o_main["dt"] / args.steps * 1e3,
+                             "value": world * o_main["N"] * args.num_steps * args.steps / o_main["dt"],
+                             "update_launch": "hipGraph" if o_main["agent"]._graph is not None else "eager",
+                             "graph_fallback": o_main["agent"].graph_fallback}
+            if shard is not None:
+                o_sh = run_workload(args, rank, world, dev, args.shard_envs_per_gpu, args.steps, args.warmup, False)
+                other["config4_shard"] = {"ms_per_step": o_sh["dt"] / args.steps * 1e3,
+                                          "value": world * o_sh["N"] * args.num_steps * args.steps / o_sh["dt"]}
+            for tag, r_alt, r_pri in (("main", o_main, run), ("config4_shard", o_sh if shard is not None else None, shard)):
+                if r_alt is None or r_pri is None or r_alt["gpu_first"] is None or r_pri["gpu_first"] is None:
+                    continue
+                wa, wp = r_alt["gpu_first"]["weights"], r_pri["gpu_first"]["weights"]
+                err = max(float(np.abs(wa[k] - wp[k]).max()) for k in wa)
+                other[tag]["first_update_max_abs_weight_diff_vs_primary"] = err
+                other[tag]["agrees_with_primary"] = bool(err <= 2e-6)
+                p2p = getattr((r_alt if alt == "p2p" else r_pri)["agent"], "_p2p", None)
+                if p2p is not None:
+                    other[tag]["p2p_status"] = p2p.status()
+        except Exception as e:       # (the same exception on every rank, or none: see above)
+            other["error"] = f"{type(e).__name__}: {e}"[:400]
+        finally:
+            os.environ["AURPPO_DP_ALLREDUCE"] = cur
     if rank != 0:
         D.shutdown()
         return
@@ -768,7 +804,8 @@ def main():
                                          f"K7 fused MLP step (variant {k7_variant})")},
            "roofline": roofline,
            # a capture that raised leaves the update running eagerly on every rank: said HERE, not only inside config
-           "graph_fallback": (agent.graph_fallback[:200] if agent.graph_fallback else None)}
+           "graph_fallback": (agent.graph_fallback[:200] if agent.graph_fallback else None),
+           "other_exchange": other}
     parity = None
     if world == 1 and not args.force_dp and args.cpu_baseline_updates > 0:
         out["cpu_baseline"], parity = cpu_baseline(args, run["data"], run["init_sd"], args.cpu_baseline_updates, run["gpu_first"])

@@ -23,20 +23,27 @@ run() {  # run <seconds> <cmd...>
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "step timed out: $*" >&2; exit $rc; fi
   return $rc
 }
-run 600 python3 bench.py > $O/bench.json 2> $O/bench.err
-tail -c 400 $O/bench.json; echo
-cd /tmp && export TMPDIR=/tmp
+# PART=1 | 2 | 3 runs a third of the list (a gpurun call is capped at 20 minutes); default: everything
+part() { [ "${PART:-all}" = all ] || [ "$PART" = "$1" ]; }
+export TMPDIR=/tmp
 prof() {  # prof <tag> <bench args...>
   local tag=$1; shift
+  cd /tmp
   run 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$tag -- python3 $R/bench.py --cpu-baseline-updates 0 "$@" > $O/${tag}_under_rocprof.json 2> $O/${tag}_rocprof.err
   cp $(ls $O/stats_$tag/*/*kernel_stats.csv | head -1) $O/${tag}_kernel_stats.csv
   rm -rf $O/stats_$tag
+  cd $R
 }
+if part 1; then
+run 600 python3 bench.py > $O/bench.json 2> $O/bench.err
+tail -c 400 $O/bench.json; echo
 prof bench --shard-envs-per-gpu 0
 prof bench_shard --envs-per-gpu 512 --shard-envs-per-gpu 0
 prof bench_default
 prof bench_nofused --no-fused-mlp
 prof bench_forcedp --force-dp
+fi
+if part 2; then
 prof bench_wide_3x128 --hidden-dim 128 --num-layers 3 --steps 30
 prof bench_wide_3x64 --hidden-dim 64 --num-layers 3 --steps 30
 prof bench_wide_2x128 --hidden-dim 128 --num-layers 2 --steps 30
@@ -45,6 +52,8 @@ for shape in "128 3" "64 3" "128 2"; do
   run 600 python3 $R/bench.py --hidden-dim $1 --num-layers $2 --steps 30 --cpu-baseline-updates 1 > $O/bench_wide_$2x$1.json 2> $O/bench_wide_$2x$1.err
 done
 run 600 python3 $R/tools/bench_wide.py > $O/wide_bench.json 2> $O/wide_bench.err
+fi
+if part 3; then
 # (every step below runs under `run`, i.e. its own timeout; a pipe into tail would swallow its exit code, so outputs go to files first)
 for v in 3 2; do AURPPO_K7_VARIANT=$v run 300 python3 $R/tools/mlp_stamps.py > $O/k7_stamps_v$v.txt 2>&1; done
 : > $O/k7_time.txt
@@ -65,5 +74,12 @@ pmc() {  # pmc <variant> <kernel> <out>
 }
 pmc 3 k_mlp_step3 mlp3_pmc.json
 pmc 2 k_mlp_step2 mlp_pmc.json
+# matrix-pipe / wave-state counters (tools/pmc_mfma.sh: its own rocprofv3 passes, --pmc + --kernel-trace only)
+cd $R
+run 900 bash tools/pmc_mfma.sh k7 k_mlp_step3 72351744 bench.py --steps 2 --warmup 2 --no-probe --cpu-baseline-updates 0 --no-parity --shard-envs-per-gpu 0 > /dev/null 2>&1
+cp gpurun_out/k7_mfma_pmc.json $O/mlp3_mfma_pmc.json
+run 900 bash tools/pmc_mfma.sh wide3x128 k_mlpw 0 bench.py --hidden-dim 128 --num-layers 3 --steps 2 --warmup 2 --no-probe --cpu-baseline-updates 0 --no-parity --shard-envs-per-gpu 0 > /dev/null 2>&1
+cp gpurun_out/wide3x128_mfma_pmc.json $O/mlp_wide3_3x128_mfma_pmc.json
+fi
 cd $R
 ls -la $O
