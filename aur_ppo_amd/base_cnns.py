@@ -6,6 +6,8 @@ The convolutions are stock PyTorch-ROCm (MIOpen); on the GPU the element-wise ta
 and one backward (csrc/pool.hip): rocprof put 53 % of robot_ppo.update's GPU time in those memory-bound passes."""
 from __future__ import annotations
 
+import os
+
 import torch
 from torch import nn
 
@@ -46,6 +48,7 @@ class base_encoder(nn.Module):
         self.conv = nn.Sequential(*mods)
 
     fused_pool = True      # K9 on CUDA tensors (False: the stock torch ops everywhere, for A/B runs)
+    fused_conv = os.environ.get("AURPPO_NO_K11") != "1"      # K11 for the hidden 3x3 convolutions on CUDA tensors (False / AURPPO_NO_K11=1: torch / MIOpen, for A/B runs)
     fused_first = True     # K10 for the first block when it runs in split form on CUDA tensors
 
     def _blocks(self, x, start, scale=None, plane=None, first_weight=None):
@@ -63,9 +66,15 @@ class base_encoder(nn.Module):
                       and mods[i + 2].stride in (2, (2, 2)) and mods[i + 2].padding in (0, (0, 0)))
             if use and triple:
                 w = first_weight if (i == start and first_weight is not None) else m.weight
-                z = torch.nn.functional.conv2d(x, w, None, stride=m.stride, padding=m.padding)
+                if self.fused_conv and w is m.weight and H.conv3x3_supported(x, m):
+                    z = H.conv3x3(x, w, m.padding[0])
+                else:
+                    z = torch.nn.functional.conv2d(x, w, None, stride=m.stride, padding=m.padding)
                 x = H.bias_relu_pool2(z, m.bias, scale if i == start else None, plane if i == start else None)
                 i += 3
+            elif use and self.fused_conv and isinstance(m, nn.Conv2d) and H.conv3x3_supported(x, m):
+                x = H.conv3x3(x, m.weight, m.padding[0]) + m.bias.reshape(1, -1, 1, 1)
+                i += 1
             else:
                 x = m(x)
                 i += 1

@@ -760,6 +760,67 @@ class _FirstBlock(torch.autograd.Function):
         return None, None, dw, db
 
 
+CONV3X3_MIN_PIXELS = 131072
+
+
+class _Conv3x3(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, pad):
+        lib = _lib_or_raise()
+        x, w = x.contiguous(), w.contiguous()
+        B, Ci, Hh, Ww = x.shape
+        Co = w.shape[0]
+        z = torch.empty((B, Co, Hh + 2 * pad - 2, Ww + 2 * pad - 2), dtype=torch.float32, device=x.device)
+        ws = _workspace("conv", lib.aurppo_conv3x3_wop_bytes(Ci, Co), x.device)
+        _check(lib.aurppo_conv3x3_f32(_ptr(x.detach()), _ptr(w.detach()), _ptr(z), B, Ci, Co, Hh, Ww, int(pad), 0,
+                                      C.c_void_p(ws.data_ptr()), _stream()), "aurppo_conv3x3_f32")
+        ctx.save_for_backward(x, w)
+        ctx.pad = int(pad)
+        return z
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib_or_raise()
+        x, w = ctx.saved_tensors
+        g = g.contiguous()
+        B, Ci, Hh, Ww = x.shape
+        Co, pad = w.shape[0], ctx.pad
+        dx = dw = None
+        if ctx.needs_input_grad[0] and Ci % 32 != 0:
+            # an input gradient with 16 output channels would leave half of every 32-wide matrix block empty: the library's kernel
+            dx = torch.ops.aten.convolution_backward(g, x, w, None, [1, 1], [pad, pad], [1, 1], False, [0, 0], 1,
+                                                     [True, False, False])[0]
+        elif ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            ws = _workspace("conv", lib.aurppo_conv3x3_wop_bytes(Co, Ci), x.device)
+            _check(lib.aurppo_conv3x3_f32(_ptr(g), _ptr(w.detach()), _ptr(dx), B, Ci, Co, g.shape[2], g.shape[3], pad, 1,
+                                          C.c_void_p(ws.data_ptr()), _stream()), "aurppo_conv3x3_f32")
+        if ctx.needs_input_grad[1]:
+            # the weight gradient stays with the library's implicit-GEMM kernels (fp32 MFMAs at 50-80 % of their pipe)
+            dw = torch.ops.aten.convolution_backward(g, x, w, None, [1, 1], [pad, pad], [1, 1], False, [0, 0], 1,
+                                                     [False, True, False])[1]
+        return dx, dw, None
+
+
+def conv3x3_supported(x, conv):
+    """K11 takes an ``nn.Conv2d`` with a 3x3 kernel, stride 1, padding 0..2 (square), no dilation / groups, on a CUDA fp32 NCHW
+    tensor, when both channel counts are multiples of 16 (forward and input gradient each need that of their own input)."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and tuple(conv.kernel_size) == (3, 3) and tuple(conv.stride) == (1, 1)
+            and tuple(conv.dilation) == (1, 1) and conv.groups == 1 and conv.padding in ((0, 0), (1, 1), (2, 2))
+            and conv.padding_mode == "zeros" and conv.in_channels % 16 == 0 and conv.out_channels % 32 == 0):
+        return False
+    # a workgroup takes 256 output pixels: below ~512 workgroups (the encoder's last 3x3 -> 1x1 layers, a rollout step's batch)
+    # the launch is a handful of long serial K loops and the library's kernels are faster
+    p = conv.padding[0]
+    return x.shape[0] * (x.shape[2] + 2 * p - 2) * (x.shape[3] + 2 * p - 2) >= CONV3X3_MIN_PIXELS
+
+
+def conv3x3(x, weight, padding):
+    """K11: ``conv2d(x, weight, None, stride=1, padding=padding)`` for a 3x3 filter on the bf16 matrix pipe (fp32 products from
+    three-way bf16 splits), forward and input gradient (src/nets/base_cnns.py:32-45's hidden convolutions)."""
+    return _Conv3x3.apply(x, weight, int(padding))
+
+
 def first_block(obs, state, weight, bias):
     """K10: ``max_pool2d(relu(conv2d(cat[obs, state tiled to a plane], weight, bias, padding=1)), 2)`` -- the first block of
     src/nets/base_cnns.py:28-31 on the input of src/models/robot_actor_critic.py:58-59 -- forward and backward without the

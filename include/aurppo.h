@@ -244,6 +244,19 @@ int aurppo_mlp_ppo_apply_parts_f32(float* params, float* grads, float* exp_avg, 
                                    float* out_norm, const float* rec, int rec_floats, const int32_t* next_idx, int next_M,
                                    void* workspace, void* stream);
 
+/* ---- K11: 3x3 convolution of the robot policy's hidden encoder blocks on the bf16 matrix pipe -----------------
+ * nn.Conv2d(Ci, Co, 3, padding = pad) WITHOUT bias (src/nets/base_cnns.py:32-45; the bias / ReLU / max-pool tail is
+ * aurppo_bias_relu_pool2_*), stride 1, NCHW fp32, as an implicit GEMM whose fp32 products are formed from three-way bf16
+ * splits (fp32-equivalent).  mode 0: z = conv2d(x, w, padding = pad), x (B, Ci, H, W) -> z (B, Co, H + 2 pad - 2, W + 2 pad - 2).
+ * mode 1: the gradient with respect to the input: x is the OUTPUT gradient (B, Co, H, W), z the input gradient
+ * (B, Ci, H + 2 - 2 pad, W + 2 - 2 pad), w the same (Co, Ci, 3, 3) filter, pad the forward padding.  The product's input
+ * channel count (Ci in mode 0, Co in mode 1) must be a multiple of 16.  wop_ws: aurppo_conv3x3_wop_bytes(input channels,
+ * output channels of the product) bytes of scratch for the filter in operand order.  (The weight gradient stays with the
+ * library's implicit-GEMM kernels, which run fp32 MFMAs at 50-80 % of their pipe.) */
+size_t aurppo_conv3x3_wop_bytes(int cin_gemm, int cout_gemm);
+int aurppo_conv3x3_f32(const float* x, const float* w, float* z, int B, int Ci_w, int Co_w, int H, int W, int pad, int mode,
+                       void* wop_ws, void* stream);
+
 /* ---- one-shot gradient all-reduce over peer memory (one process per GPU; SURVEY 8e plan B) ------------------
  * Where it sits in the reference: between loss.backward() and clip_grad_norm_ (src/ppo.py:266-268); upstream is
  * single-process, so there is no call to cite -- the semantics are "mean of the ranks' gradients, identical bits on

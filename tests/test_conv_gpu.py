@@ -1,0 +1,78 @@
+"""GPU: K11 (csrc/conv.hip) -- the hidden 3x3 convolutions of the robot policy's encoder (src/nets/base_cnns.py:32-45) as an implicit
+GEMM on bf16 MFMAs over three-way splits -- against a plain PyTorch fp32 reference of the same op (torch's conv2d with MIOpen's
+Winograd solvers disabled would still be a library kernel: the reference here is the fp64 convolution rounded to fp32, which
+both fp32 implementations must meet to a few ulps of the sum of |products|)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(x, w, pad):
+    return torch.nn.functional.conv2d(x.double(), w.double(), None, stride=1, padding=pad)
+
+
+# (B, Ci, Co, H, W, pad): the encoder's hidden layers at a small batch (config 3 and config 5 sizes), odd sizes, a batch that does
+# not fill a 32-pixel block, output channels that are not a multiple of 32, pixel blocks that straddle image boundaries
+SHAPES = [(4, 16, 32, 64, 64, 1), (4, 32, 64, 32, 32, 1), (4, 64, 128, 16, 16, 1), (4, 128, 256, 8, 8, 1), (4, 256, 256, 8, 8, 0),
+          (8, 256, 128, 3, 3, 0), (3, 16, 32, 42, 42, 1), (3, 32, 64, 21, 21, 1), (3, 64, 128, 10, 10, 1), (5, 128, 256, 5, 5, 0),
+          (1, 16, 16, 5, 7, 1), (2, 32, 48, 9, 4, 0), (1, 48, 80, 6, 6, 2), (7, 16, 96, 3, 3, 1)]
+
+
+@pytest.mark.parametrize("B,Ci,Co,H,W,pad", SHAPES)
+def test_conv3x3_forward_and_gradients_match_the_fp64_convolution(B, Ci, Co, H, W, pad):
+    from aur_ppo_amd import hip_ops as Hh
+    g = torch.Generator(device="cuda").manual_seed(B * 1000 + Ci + Co + H)
+    x = torch.randn(B, Ci, H, W, device="cuda", generator=g, requires_grad=True)
+    w = (torch.randn(Co, Ci, 3, 3, device="cuda", generator=g) * (2.0 / (9 * Ci)) ** 0.5).requires_grad_(True)
+    z = Hh.conv3x3(x, w, pad)
+    zr = _ref(x.detach(), w.detach(), pad)
+    assert z.shape == zr.shape
+    # scale of the rounding: the sum of |products| behind an output element
+    mag = torch.nn.functional.conv2d(x.detach().abs().double(), w.detach().abs().double(), None, padding=pad)
+    err = ((z.double() - zr).abs() / mag.clamp_min(1e-30)).max().item()
+    assert err <= 4e-7, f"forward: {err:.3e} of sum|ab|"
+    gz = torch.randn(z.shape, device="cuda", generator=g)
+    z.backward(gz)
+    xd, wd = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
+    torch.nn.functional.conv2d(xd, wd, None, padding=pad).backward(gz.double())
+    # input gradient: K11 (mode 1); scale: sum |g| |w| behind an input element
+    magx = torch.nn.functional.conv_transpose2d(gz.abs().double(), w.detach().abs().double(), None, padding=pad)
+    errx = ((x.grad.double() - xd.grad).abs() / magx.clamp_min(1e-30)).max().item()
+    assert errx <= 4e-7, f"input gradient: {errx:.3e} of sum|ab|"
+    # weight gradient: the library's kernel behind the same autograd node (fp32 sums over B * H * W terms)
+    np.testing.assert_allclose(w.grad.cpu().numpy(), wd.grad.float().cpu().numpy(), rtol=2e-4, atol=2e-5 * float(wd.grad.abs().max()))
+
+
+def test_conv3x3_equals_torch_conv2d_to_2e5_on_encoder_data():
+    """The tolerance K10 is held to (2e-5 against torch's own fp32 convolution), at a hidden block's shape."""
+    from aur_ppo_amd import hip_ops as Hh
+    g = torch.Generator(device="cuda").manual_seed(4)
+    x = torch.rand(16, 32, 32, 32, device="cuda", generator=g)
+    w = torch.randn(64, 32, 3, 3, device="cuda", generator=g) * 0.08
+    z = Hh.conv3x3(x, w, 1)
+    zt = torch.nn.functional.conv2d(x, w, None, padding=1)
+    torch.testing.assert_close(z, zt, rtol=2e-5, atol=2e-5)
+
+
+def test_encoder_with_k11_matches_the_stock_encoder(monkeypatch):
+    """base_encoder with K11 for its hidden convolutions against the same module on torch's convolutions: features and every
+    parameter gradient."""
+    from aur_ppo_amd import hip_ops as Hh
+    from aur_ppo_amd.base_cnns import base_encoder
+    monkeypatch.setattr(Hh, "CONV3X3_MIN_PIXELS", 1)       # (the size rule would hand this small batch to the library)
+    torch.manual_seed(0)
+    enc = base_encoder(obs_shape=(2, 128, 128), out_dim=128).cuda()
+    obs = torch.rand(6, 1, 128, 128, device="cuda")
+    state = (torch.rand(6, device="cuda") < 0.5).float()
+    outs = []
+    for fused in (True, False):
+        enc.fused_conv = fused
+        enc.zero_grad()
+        y = enc.forward_split(obs, state)
+        y.square().sum().backward()
+        outs.append((y.detach().clone(), [p.grad.detach().clone() for p in enc.parameters()]))
+    torch.testing.assert_close(outs[0][0], outs[1][0], rtol=2e-5, atol=2e-5)
+    for a, b in zip(outs[0][1], outs[1][1]):
+        torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-5 * float(b.abs().max()) + 1e-7)
