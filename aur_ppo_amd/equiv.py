@@ -23,6 +23,7 @@ An 84x84 variant (BASELINE config 5) keeps every spatial op rotation-symmetric: 
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 from torch import nn
@@ -67,8 +68,18 @@ class C4Conv(nn.Module):
     def expanded_bias(self):
         return self.bias.repeat_interleave(4) if self.out_type == "regular" else self.bias
 
+    fused_conv = os.environ.get("AURPPO_NO_K11") != "1"      # K11 (csrc/conv.hip) for the expanded filter bank when its shape rule holds
+
     def forward(self, x, with_bias=True):
-        return F.conv2d(x, self.expanded_weight(), self.expanded_bias() if with_bias else None, padding=self.padding)
+        w = self.expanded_weight()
+        if self.fused_conv and x.is_cuda and self.kernel_size == 3:
+            from . import hip_ops as H
+            if H.conv3x3_ok(x, w.shape[1], w.shape[0], self.padding):
+                # the expanded C4 filter bank is a dense 3x3 convolution over 4 x fields channels: the contraction north_star
+                # reserves the matrix cores for.  The gradient reaches the free parameters through expanded_weight's autograd.
+                z = H.conv3x3(x, w, self.padding)
+                return z + self.expanded_bias().reshape(1, -1, 1, 1) if with_bias else z
+        return F.conv2d(x, w, self.expanded_bias() if with_bias else None, padding=self.padding)
 
 
 class GroupPool(nn.Module):

@@ -802,17 +802,22 @@ class _Conv3x3(torch.autograd.Function):
         return dx, dw, None
 
 
-def conv3x3_supported(x, conv):
-    """K11 takes an ``nn.Conv2d`` with a 3x3 kernel, stride 1, padding 0..2 (square), no dilation / groups, on a CUDA fp32 NCHW
-    tensor, when both channel counts are multiples of 16 (forward and input gradient each need that of their own input)."""
-    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and tuple(conv.kernel_size) == (3, 3) and tuple(conv.stride) == (1, 1)
-            and tuple(conv.dilation) == (1, 1) and conv.groups == 1 and conv.padding in ((0, 0), (1, 1), (2, 2))
-            and conv.padding_mode == "zeros" and conv.in_channels % 16 == 0 and conv.out_channels % 32 == 0):
+def conv3x3_ok(x, cin, cout, pad):
+    """K11's shape rule for ``conv2d(x, w (cout, cin, 3, 3), padding=pad)``, stride 1: a CUDA fp32 NCHW tensor, cin a multiple
+    of 16 (one k-step = 16 channels of a tap), cout a multiple of 32 (whole matrix blocks), and enough output pixels -- a workgroup
+    takes 256 of them, and below ~512 workgroups (the encoder's last 3x3 -> 1x1 layers) the launch is a handful of long serial K
+    loops that the library's kernels beat."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == cin and cin % 16 == 0 and cout % 32 == 0
+            and pad in (0, 1, 2)):
         return False
-    # a workgroup takes 256 output pixels: below ~512 workgroups (the encoder's last 3x3 -> 1x1 layers, a rollout step's batch)
-    # the launch is a handful of long serial K loops and the library's kernels are faster
-    p = conv.padding[0]
-    return x.shape[0] * (x.shape[2] + 2 * p - 2) * (x.shape[3] + 2 * p - 2) >= CONV3X3_MIN_PIXELS
+    return x.shape[0] * (x.shape[2] + 2 * pad - 2) * (x.shape[3] + 2 * pad - 2) >= CONV3X3_MIN_PIXELS
+
+
+def conv3x3_supported(x, conv):
+    """``conv3x3_ok`` for an ``nn.Conv2d``: 3x3 kernel, stride 1, square zero padding 0..2, no dilation / groups."""
+    return (tuple(conv.kernel_size) == (3, 3) and tuple(conv.stride) == (1, 1) and tuple(conv.dilation) == (1, 1) and conv.groups == 1
+            and conv.padding in ((0, 0), (1, 1), (2, 2)) and conv.padding_mode == "zeros"
+            and conv3x3_ok(x, conv.in_channels, conv.out_channels, conv.padding[0]))
 
 
 def conv3x3(x, weight, padding):
