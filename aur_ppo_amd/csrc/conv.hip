@@ -87,7 +87,11 @@ __device__ __forceinline__ void dma16(const void* src, void* dst_wave_uniform) {
 // k-steps at a time (kKC x NB x 3 KB) are brought into LDS ONCE per workgroup by LDS-DMA, double-buffered, one barrier per chunk;
 // every wave reads its B fragments from there (with each wave fetching its own from L2, the CU's L2 path -- about 16 B per
 // cycle -- carried 12 KB per wave and k-step: 61-120 TFLOP/s, no better than the library).
-template <int NB>      // 32-channel blocks of the channel group (1, 2 or 4)
+// BUF (the input tensor is under 4 GB): the A values come through buffer loads -- per lane ONE 32-bit byte offset per tap and
+// pixel block (out-of-image taps get an offset past the buffer: the hardware returns 0), the channel's offset in a scalar
+// register.  The first version formed a 64-bit address and a zero select per value: 288 vector instructions per k-step against
+// 48 matrix instructions, and the two barely overlap (SQ_VALU_MFMA_COEXEC_CYCLES 7 % of the matrix time, profiles/r04).
+template <int NB, bool BUF>      // NB: 32-channel blocks of the channel group (1, 2 or 4)
 __global__ __launch_bounds__(kConvThreads, 2) void k_conv3x3(const ConvArgs a) {
     constexpr int kChunkBytes = kKC * NB * 3 * 1024;
     constexpr int kLdsBytes = 2 * kChunkBytes > (kConvThreads / kWave) * 32 * kTileLd * 4 ? 2 * kChunkBytes
@@ -140,6 +144,12 @@ __global__ __launch_bounds__(kConvThreads, 2) void k_conv3x3(const ConvArgs a) {
             for (int e = 0; e < 16; ++e) acc[mb][nb][e] = 0.0f;
 
     // the A values of one k-step: this lane's 8 channels of the tap's input pixel, for both pixel blocks
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.x), 0, BUF ? (unsigned)((size_t)a.B * a.Cin * HW * 4) : 0u, 0x00020000);
+    unsigned pix_off[kMB];           // BUF: byte offset of (b, channel 8 h, y - pad, x - pad) -- may wrap below zero, used with a valid tap only
+#pragma unroll
+    for (int mb = 0; mb < kMB; ++mb)
+        pix_off[mb] = (unsigned)((img[mb] + (size_t)(8 * h) * HW) * 4) + (unsigned)(((yy[mb] - a.pad) * a.W + (xx[mb] - a.pad)) * 4);
     auto load_a = [&](int ks, float (&v)[kMB][8]) {
         const int tap = ks / CG, cg = ks - tap * CG;
         const int ky = tap / 3, kx = tap - 3 * ky;
@@ -147,18 +157,27 @@ __global__ __launch_bounds__(kConvThreads, 2) void k_conv3x3(const ConvArgs a) {
         for (int mb = 0; mb < kMB; ++mb) {
             const int iy = yy[mb] + ky - a.pad, ix = xx[mb] + kx - a.pad;
             const bool inb = valid[mb] && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-            const size_t at = img[mb] + (size_t)(cg * 16 + 8 * h) * HW + (size_t)(inb ? iy * a.W + ix : 0);
+            if (BUF) {
+                const unsigned vo = inb ? pix_off[mb] + (unsigned)((ky * a.W + kx) * 4) : 0xfffffff0u;     // past the buffer: reads 0
+                const int so0 = cg * 16 * HW * 4;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float t = a.x[inb ? at + (size_t)j * HW : 0];
-                v[mb][j] = inb ? t : 0.0f;
+                for (int j = 0; j < 8; ++j)
+                    v[mb][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, vo, so0 + j * HW * 4, 0));
+            } else {
+                const size_t at = img[mb] + (size_t)(cg * 16 + 8 * h) * HW + (size_t)(inb ? iy * a.W + ix : 0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float t = a.x[inb ? at + (size_t)j * HW : 0];
+                    v[mb][j] = inb ? t : 0.0f;
+                }
             }
         }
     };
     const int n_chunks = (KS + kKC - 1) / kKC;
-    float cur[kMB][8], nxt[kMB][8];
+    float abuf[2][kMB][8];           // k-step ks computes from abuf[ks & 1] while abuf[(ks + 1) & 1] is in flight (kKC = 2: the parity is kk's)
+    static_assert(kKC == 2, "the A registers ping-pong on the k-step's position inside its chunk");
     stage(0, 0);
-    load_a(0, cur);
+    load_a(0, abuf[0]);
     asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // (the DMA pieces are older than the 16 loads of load_a)
     __syncthreads();
     for (int kc = 0; kc < n_chunks; ++kc) {
@@ -168,7 +187,8 @@ __global__ __launch_bounds__(kConvThreads, 2) void k_conv3x3(const ConvArgs a) {
         for (int kk = 0; kk < kKC; ++kk) {
             const int ks = kc * kKC + kk;
             if (ks < KS) {
-                if (ks + 1 < KS) load_a(ks + 1, nxt);
+                float (&cur)[kMB][8] = abuf[kk];
+                if (ks + 1 < KS) load_a(ks + 1, abuf[kk ^ 1]);
                 Frag3 A[kMB];
 #pragma unroll
                 for (int mb = 0; mb < kMB; ++mb) {
@@ -189,10 +209,6 @@ __global__ __launch_bounds__(kConvThreads, 2) void k_conv3x3(const ConvArgs a) {
 #pragma unroll
                     for (int mb = 0; mb < kMB; ++mb) acc[mb][nb] = mma32x3(A[mb], Bf, acc[mb][nb]);
                 }
-#pragma unroll
-                for (int mb = 0; mb < kMB; ++mb)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) cur[mb][j] = nxt[mb][j];
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the next chunk's DMA pieces (and the A values) have landed
@@ -262,9 +278,18 @@ extern "C" int aurppo_conv3x3_f32(const float* x, const float* w, float* z, int 
     const int n_ng = (nblk + NB - 1) / NB;
     const long long grid = n_mb4 * n_ng;
     AURPPO_REQUIRE(grid < (1ll << 31), AURPPO_ESHAPE, "aurppo_conv3x3_f32: grid too large");
-    if (NB == 4) hipLaunchKernelGGL(k_conv3x3<4>, dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
-    else if (NB == 2) hipLaunchKernelGGL(k_conv3x3<2>, dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
-    else hipLaunchKernelGGL(k_conv3x3<1>, dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+    // buffer loads address 32 bits: inputs under 4 GB (minus the slack a negative tap offset may wrap through); larger ones keep 64-bit addresses
+    const bool buf = (size_t)B * cin * H * W * 4 < ((size_t)1 << 32) - ((size_t)1 << 20);
+    const dim3 g((unsigned)grid), blk(kConvThreads);
+    if (buf) {
+        if (NB == 4) hipLaunchKernelGGL((k_conv3x3<4, true>), g, blk, 0, s, a);
+        else if (NB == 2) hipLaunchKernelGGL((k_conv3x3<2, true>), g, blk, 0, s, a);
+        else hipLaunchKernelGGL((k_conv3x3<1, true>), g, blk, 0, s, a);
+    } else {
+        if (NB == 4) hipLaunchKernelGGL((k_conv3x3<4, false>), g, blk, 0, s, a);
+        else if (NB == 2) hipLaunchKernelGGL((k_conv3x3<2, false>), g, blk, 0, s, a);
+        else hipLaunchKernelGGL((k_conv3x3<1, false>), g, blk, 0, s, a);
+    }
     AURPPO_LAUNCH_CHECK("k_conv3x3");
     return AURPPO_OK;
 }
