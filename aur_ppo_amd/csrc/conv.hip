@@ -50,8 +50,8 @@ __device__ __forceinline__ int acc_row_c(int e, int lane) { return (e & 3) + 8 *
 // 1 (input gradient): the product's "input" channels are the forward pass's OUTPUT channels: B[k = (tap, co)][n = ci] =
 // W[co][ci][8 - tap].  cin_gemm / cout_gemm are the product's own channel counts (cin_gemm a multiple of 16).
 __global__ __launch_bounds__(256) void k_conv_prep(const float* __restrict__ w, int Co_w, int Ci_w, int cin_gemm, int cout_gemm,
-                                                   int transpose_flip, unsigned short* __restrict__ wop) {
-    const int CG = cin_gemm >> 4, KS = 9 * CG, NBLK = (cout_gemm + 31) >> 5;
+                                                   int transpose_flip, unsigned short* __restrict__ wop, int taps) {
+    const int CG = cin_gemm >> 4, KS = taps * CG, NBLK = (cout_gemm + 31) >> 5;
     const long long total = (long long)NBLK * KS * 64 * 8;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
         const int j = (int)(e & 7), lane = (int)((e >> 3) & 63);
@@ -61,8 +61,8 @@ __global__ __launch_bounds__(256) void k_conv_prep(const float* __restrict__ w, 
         const int n = nblk * 32 + (lane & 31), k = cg * 16 + 8 * (lane >> 5) + j;
         float v = 0.0f;
         if (n < cout_gemm) {
-            if (!transpose_flip) v = w[((size_t)n * Ci_w + k) * 9 + tap];               // W[co = n][ci = k][tap]
-            else v = w[((size_t)k * Ci_w + n) * 9 + (8 - tap)];                          // W[co = k][ci = n][flipped tap]
+            if (!transpose_flip) v = w[((size_t)n * Ci_w + k) * taps + tap];               // W[co = n][ci = k][tap]
+            else v = w[((size_t)k * Ci_w + n) * taps + (taps - 1 - tap)];                  // W[co = k][ci = n][flipped tap]
         }
         unsigned p0, p1, p2;
         split3(v, 0.0f, p0, p1, p2);
@@ -238,6 +238,119 @@ __global__ __launch_bounds__(kConvThreads, 2) void k_conv3x3(const ConvArgs a) {
         }
 }
 
+// ---- the same product for nn.Linear (src/nets/nets.py:21-27,33-39,45-51 with hidden_dim > 128, which the fused K7 / K7w steps do not
+// cover): y (M, N) = x (M, K) . B (K, N), x row-major -- a 1 x 1 "convolution" whose pixels are the minibatch's rows.  Same
+// filter staging and matrix loop as k_conv3x3; the A values of a k-step are 32 contiguous bytes per lane (two 16-byte loads), and
+// the accumulator's lane-per-column layout already matches the row-major output (32 lanes = 128 contiguous bytes): no LDS tile.
+struct LinArgs {
+    const float* x;                  // (M, K)
+    const unsigned short* wop;       // [n-block][k-step][plane][lane][8]
+    float* y;                        // (M, N)
+    long long M;
+    int K, N, n_mb;
+};
+
+template <int NB>
+__global__ __launch_bounds__(kConvThreads, 2) void k_linear(const LinArgs a) {
+    constexpr int kChunkBytes = kKC * NB * 3 * 1024;
+    __shared__ __attribute__((aligned(16))) char s_b[2 * kChunkBytes];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mbq = (int)(blockIdx.x % (unsigned)a.n_mb), ng = (int)(blockIdx.x / (unsigned)a.n_mb);
+    const int h = lane >> 5;
+    const int KS = a.K >> 4;
+    long long m0[kMB];
+    const float* row[kMB];
+    bool valid[kMB];
+#pragma unroll
+    for (int mb = 0; mb < kMB; ++mb) {
+        m0[mb] = (((long long)mbq * 4 + w) * kMB + mb) * 32;
+        const long long m = m0[mb] + (lane & 31);
+        valid[mb] = m < a.M;
+        row[mb] = a.x + (size_t)(valid[mb] ? m : 0) * a.K + 8 * h;
+    }
+    const char* const wgrp = reinterpret_cast<const char*>(a.wop) + (size_t)(ng * NB) * KS * 3 * 1024;
+    auto stage = [&](int kc, int buf) {
+        char* const dst = s_b + buf * kChunkBytes;
+#pragma unroll
+        for (int f = 0; f < kKC * NB * 3; ++f) {
+            if ((f & 3) != w) continue;
+            const int pl = f % 3, nb = (f / 3) % NB, kk = f / (3 * NB);
+            const int ks = kc * kKC + kk;
+            if (ks < KS) dma16(wgrp + ((size_t)(nb * KS + ks) * 3 + pl) * 1024 + lane * 16, dst + f * 1024);
+        }
+    };
+    f32x16c acc[kMB][NB];
+#pragma unroll
+    for (int mb = 0; mb < kMB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mb][nb][e] = 0.0f;
+    auto load_a = [&](int ks, float4 (&v)[kMB][2]) {
+#pragma unroll
+        for (int mb = 0; mb < kMB; ++mb) {
+            const float4* p = reinterpret_cast<const float4*>(row[mb] + ks * 16);
+            v[mb][0] = p[0];
+            v[mb][1] = p[1];
+        }
+    };
+    const int n_chunks = (KS + kKC - 1) / kKC;
+    float4 abuf[2][kMB][2];
+    stage(0, 0);
+    load_a(0, abuf[0]);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");       // (the DMA pieces are older than the 4 loads of load_a)
+    __syncthreads();
+    for (int kc = 0; kc < n_chunks; ++kc) {
+        if (kc + 1 < n_chunks) stage(kc + 1, (kc + 1) & 1);
+        const char* const bsrc = s_b + (kc & 1) * kChunkBytes + lane * 16;
+#pragma unroll
+        for (int kk = 0; kk < kKC; ++kk) {
+            const int ks = kc * kKC + kk;
+            if (ks < KS) {
+                float4 (&cur)[kMB][2] = abuf[kk];
+                if (ks + 1 < KS) load_a(ks + 1, abuf[kk ^ 1]);
+                Frag3 A[kMB];
+#pragma unroll
+                for (int mb = 0; mb < kMB; ++mb) {
+                    const float c[8] = {cur[mb][0].x, cur[mb][0].y, cur[mb][0].z, cur[mb][0].w, cur[mb][1].x, cur[mb][1].y, cur[mb][1].z, cur[mb][1].w};
+                    unsigned p[4][3];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) split3(valid[mb] ? c[2 * q] : 0.0f, valid[mb] ? c[2 * q + 1] : 0.0f, p[q][0], p[q][1], p[q][2]);
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        const u32x4 v = {p[0][pl], p[1][pl], p[2][pl], p[3][pl]};
+                        A[mb].p[pl] = __builtin_bit_cast(bf16x8, v);
+                    }
+                }
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    Frag3 Bf;
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) Bf.p[pl] = *reinterpret_cast<const bf16x8*>(bsrc + ((kk * NB + nb) * 3 + pl) * 1024);
+#pragma unroll
+                    for (int mb = 0; mb < kMB; ++mb) acc[mb][nb] = mma32x3(A[mb], Bf, acc[mb][nb]);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+#pragma unroll
+    for (int mb = 0; mb < kMB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int col = (ng * NB + nb) * 32 + (lane & 31);
+            if (col < a.N) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const long long r = m0[mb] + acc_row_c(e, lane);
+                    if (r < a.M) a.y[(size_t)r * a.N + col] = acc[mb][nb][e];
+                }
+            }
+        }
+}
+
 }  // namespace
 
 extern "C" size_t aurppo_conv3x3_wop_bytes(int cin_gemm, int cout_gemm) {
@@ -263,7 +376,7 @@ extern "C" int aurppo_conv3x3_f32(const float* x, const float* w, float* z, int 
                    "aurppo_conv3x3_f32: operand too large / workspace not 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     unsigned short* wop = reinterpret_cast<unsigned short*>(wop_ws);
-    hipLaunchKernelGGL(k_conv_prep, dim3(128), dim3(256), 0, s, w, Co_w, Ci_w, cin, cout, mode, wop);
+    hipLaunchKernelGGL(k_conv_prep, dim3(128), dim3(256), 0, s, w, Co_w, Ci_w, cin, cout, mode, wop, 9);
     AURPPO_LAUNCH_CHECK("k_conv_prep");
     ConvArgs a;
     a.x = x; a.wop = wop; a.z = z;
@@ -291,5 +404,37 @@ extern "C" int aurppo_conv3x3_f32(const float* x, const float* w, float* z, int 
         else hipLaunchKernelGGL((k_conv3x3<1, false>), g, blk, 0, s, a);
     }
     AURPPO_LAUNCH_CHECK("k_conv3x3");
+    return AURPPO_OK;
+}
+
+// mode 0: y (M, N_w) = x (M, K_w) . w (N_w, K_w)^T      -- nn.Linear without its bias; K_w a multiple of 16
+// mode 1: y (M, K_w) = x (M, N_w) . w (N_w, K_w)         -- the gradient with respect to the input (x is dY); N_w a multiple of 16
+// wop_ws: aurppo_conv3x3_wop_bytes(product's K, product's N) / 9 bytes suffice; the same function's size is accepted.
+extern "C" int aurppo_linear_f32(const float* x, const float* w, float* y, long long M, int K_w, int N_w, int mode, void* wop_ws,
+                                 void* stream) {
+    AURPPO_REQUIRE(x && w && y && wop_ws, AURPPO_EINVAL, "aurppo_linear_f32: null pointer");
+    AURPPO_REQUIRE(mode == 0 || mode == 1, AURPPO_EINVAL, "aurppo_linear_f32: mode %d", mode);
+    const int K = mode == 0 ? K_w : N_w, N = mode == 0 ? N_w : K_w;
+    AURPPO_REQUIRE(M > 0 && K > 0 && N > 0 && K % 16 == 0, AURPPO_ESHAPE,
+                   "aurppo_linear_f32: M=%lld, inner dimension %d (a multiple of 16), %d columns", M, K, N);
+    AURPPO_REQUIRE(aligned_to(x, 16) && aligned_to(wop_ws, 16), AURPPO_EINVAL, "aurppo_linear_f32: x / workspace not 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    unsigned short* wop = reinterpret_cast<unsigned short*>(wop_ws);
+    // filter in operand order: forward B[k][n] = w[n][k]; input gradient B[k = n_w][n = k_w] = w[k][n] (k_conv_prep, one tap)
+    hipLaunchKernelGGL(k_conv_prep, dim3(64), dim3(256), 0, s, w, N_w, K_w, K, N, mode, wop, 1);
+    AURPPO_LAUNCH_CHECK("k_conv_prep");
+    LinArgs a;
+    a.x = x; a.wop = wop; a.y = y; a.M = M; a.K = K; a.N = N;
+    const long long n_mb = (M + 32 * 4 * kMB - 1) / (32 * 4 * kMB);
+    const int nblk = (N + 31) / 32;
+    const int NB = nblk >= 4 ? 4 : (nblk >= 2 ? 2 : 1);
+    const int n_ng = (nblk + NB - 1) / NB;
+    AURPPO_REQUIRE(n_mb * n_ng < (1ll << 31), AURPPO_ESHAPE, "aurppo_linear_f32: grid too large");
+    a.n_mb = (int)n_mb;
+    const dim3 g((unsigned)(n_mb * n_ng)), blk(kConvThreads);
+    if (NB == 4) hipLaunchKernelGGL(k_linear<4>, g, blk, 0, s, a);
+    else if (NB == 2) hipLaunchKernelGGL(k_linear<2>, g, blk, 0, s, a);
+    else hipLaunchKernelGGL(k_linear<1>, g, blk, 0, s, a);
+    AURPPO_LAUNCH_CHECK("k_linear");
     return AURPPO_OK;
 }

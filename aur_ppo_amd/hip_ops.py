@@ -826,6 +826,30 @@ def conv3x3(x, weight, padding):
     return _Conv3x3.apply(x, weight, int(padding))
 
 
+LINEAR_MIN_ROWS = 32768
+
+
+def linear_ok(x, in_features, out_features):
+    """K11's row-major sibling takes ``x (M, in) @ w (out, in).T`` on a CUDA fp32 contiguous matrix when the inner dimension is a
+    multiple of 16, the output width a multiple of 32, and there are enough rows to fill the chip (a workgroup takes 256)."""
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] == in_features and in_features % 16 == 0
+            and out_features % 32 == 0 and x.shape[0] >= LINEAR_MIN_ROWS)
+
+
+def linear_nobias(x, w, mode=0):
+    """mode 0: ``x @ w.T``; mode 1: ``x @ w`` (the gradient of mode 0 with respect to its input, x being dY) -- fp32 products formed
+    from three-way bf16 splits on the MFMA pipe (csrc/conv.hip::k_linear)."""
+    lib = _lib_or_raise()
+    x, w = x.contiguous(), w.contiguous()
+    M = x.shape[0]
+    Nw, Kw = w.shape
+    y = torch.empty((M, Nw if mode == 0 else Kw), dtype=torch.float32, device=x.device)
+    ws = _workspace("conv", lib.aurppo_conv3x3_wop_bytes(Kw if mode == 0 else Nw, Nw if mode == 0 else Kw), x.device)
+    _check(lib.aurppo_linear_f32(_ptr(x), _ptr(w), _ptr(y), M, Kw, Nw, int(mode), C.c_void_p(ws.data_ptr()), _stream()),
+           "aurppo_linear_f32")
+    return y
+
+
 def first_block(obs, state, weight, bias):
     """K10: ``max_pool2d(relu(conv2d(cat[obs, state tiled to a plane], weight, bias, padding=1)), 2)`` -- the first block of
     src/nets/base_cnns.py:28-31 on the input of src/models/robot_actor_critic.py:58-59 -- forward and backward without the

@@ -5,10 +5,22 @@ These run as stock PyTorch-ROCm GEMMs (hipBLASLt); they are host code, not custo
 from __future__ import annotations
 
 import math
+import os
 
 import numpy as np
 import torch
 from torch import nn
+
+
+def _bf16x3_linear(x, in_features, out_features):
+    """Route this product through csrc/conv.hip::k_linear?  Off by default: measured through ``bench.py --hidden-dim 256 --num-layers 2``
+    (the per-op path these layers run on) the update took 40.5 ms with it against 39.1 ms on the library's GEMMs -- that path is
+    bound by its ~100 launches and element-wise passes per minibatch, and the separate bias pass this route adds costs what the
+    faster product saves.  ``AURPPO_LINEAR_BF16X3=1`` switches it on (tests/test_conv_gpu.py holds it to the fp64 product)."""
+    if not x.is_cuda or os.environ.get("AURPPO_LINEAR_BF16X3") != "1":
+        return False
+    from . import hip_ops as H
+    return H.linear_ok(x, in_features, out_features)
 
 
 class _LinearSplitK(torch.autograd.Function):
@@ -26,13 +38,24 @@ class _LinearSplitK(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
+        if _bf16x3_linear(x, weight.shape[1], weight.shape[0]):
+            # layers the fused steps do not cover (hidden_dim > 128): the product on bf16 MFMAs over three-way splits
+            # (csrc/conv.hip::k_linear, fp32-equivalent) instead of the library's fp32 GEMM at 0.35 of the fp32 MFMA peak
+            from . import hip_ops as H
+            return H.linear_nobias(x.detach(), weight.detach(), 0) + bias
         return torch.nn.functional.linear(x, weight, bias)
 
     @staticmethod
     def backward(ctx, gy):
         x, weight = ctx.saved_tensors
         gy = gy.contiguous()
-        gx = gy @ weight if ctx.needs_input_grad[0] else None
+        gx = None
+        if ctx.needs_input_grad[0]:
+            if _bf16x3_linear(gy, weight.shape[0], weight.shape[1]):
+                from . import hip_ops as H
+                gx = H.linear_nobias(gy, weight.detach(), 1)
+            else:
+                gx = gy @ weight
         m = x.shape[0]
         s = _LinearSplitK.SLABS
         if m % s == 0 and m >= _LinearSplitK.MIN_ROWS:

@@ -257,6 +257,13 @@ size_t aurppo_conv3x3_wop_bytes(int cin_gemm, int cout_gemm);
 int aurppo_conv3x3_f32(const float* x, const float* w, float* z, int B, int Ci_w, int Co_w, int H, int W, int pad, int mode,
                        void* wop_ws, void* stream);
 
+/* nn.Linear without its bias on the same arithmetic (the MLP policies wider than the fused steps cover, hidden_dim > 128:
+ * src/nets/nets.py:21-27,33-39,45-51 per layer).  mode 0: y (M, N_w) = x (M, K_w) . w (N_w, K_w)^T, K_w a multiple of 16;
+ * mode 1 (gradient with respect to the input; x is dY): y (M, K_w) = x (M, N_w) . w, N_w a multiple of 16.  Row-major fp32.
+ * wop_ws: aurppo_conv3x3_wop_bytes(inner dimension, columns) bytes. */
+int aurppo_linear_f32(const float* x, const float* w, float* y, long long M, int K_w, int N_w, int mode, void* wop_ws,
+                      void* stream);
+
 /* ---- one-shot gradient all-reduce over peer memory (one process per GPU; SURVEY 8e plan B) ------------------
  * Where it sits in the reference: between loss.backward() and clip_grad_norm_ (src/ppo.py:266-268); upstream is
  * single-process, so there is no call to cite -- the semantics are "mean of the ranks' gradients, identical bits on

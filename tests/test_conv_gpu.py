@@ -76,3 +76,38 @@ def test_encoder_with_k11_matches_the_stock_encoder(monkeypatch):
     torch.testing.assert_close(outs[0][0], outs[1][0], rtol=2e-5, atol=2e-5)
     for a, b in zip(outs[0][1], outs[1][1]):
         torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-5 * float(b.abs().max()) + 1e-7)
+
+
+@pytest.mark.parametrize("M,K,N", [(32768, 64, 256), (40000, 256, 256), (33000, 256, 96), (32768, 16, 32), (70001, 48, 160)])
+def test_linear_forward_and_input_gradient_match_the_fp64_product(M, K, N, monkeypatch):
+    """csrc/conv.hip::k_linear (nn.Linear's product for the MLP shapes the fused steps do not cover) against the fp64 matrix product:
+    the fp32 rounding level of the sum of |products|; through nets._Linear the module's forward / backward use it."""
+    from aur_ppo_amd import hip_ops as Hh
+    from aur_ppo_amd import nets
+    g = torch.Generator(device="cuda").manual_seed(M + K + N)
+    x = torch.randn(M, K, device="cuda", generator=g)
+    w = torch.randn(N, K, device="cuda", generator=g) * (1.0 / K) ** 0.5
+    y = Hh.linear_nobias(x, w, 0)
+    yr = x.double() @ w.double().t()
+    mag = x.abs().double() @ w.abs().double().t()
+    assert ((y.double() - yr).abs() / mag).max().item() <= 4e-7
+    if N % 16 == 0 and K % 32 == 0:
+        gy = torch.randn(M, N, device="cuda", generator=g)
+        gx = Hh.linear_nobias(gy, w, 1)
+        gxr = gy.double() @ w.double()
+        magx = gy.abs().double() @ w.abs().double()
+        assert ((gx.double() - gxr).abs() / magx).max().item() <= 4e-7
+    # the module: same parameters, K-linear forward + input gradient, split-batch weight gradient
+    monkeypatch.setenv("AURPPO_LINEAR_BF16X3", "1")
+    lin = nets._Linear(K, N).cuda()
+    xin = x.clone().requires_grad_(True)
+    out = lin(xin)
+    out.square().sum().backward()
+    ref = torch.nn.Linear(K, N).cuda()
+    ref.load_state_dict(lin.state_dict())
+    xr = x.clone().requires_grad_(True)
+    outr = ref(xr)
+    outr.square().sum().backward()
+    torch.testing.assert_close(out, outr, rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(xin.grad, xr.grad, rtol=2e-4, atol=2e-5 * float(xr.grad.abs().max()))
+    torch.testing.assert_close(lin.weight.grad, ref.weight.grad, rtol=2e-4, atol=2e-5 * float(ref.weight.grad.abs().max()))
