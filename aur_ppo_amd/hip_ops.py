@@ -786,7 +786,7 @@ class _Conv3x3(torch.autograd.Function):
         B, Ci, Hh, Ww = x.shape
         Co, pad = w.shape[0], ctx.pad
         dx = dw = None
-        if ctx.needs_input_grad[0] and Ci % 32 != 0:
+        if ctx.needs_input_grad[0] and Ci % 32 != 0 and os.environ.get("AURPPO_K11_DGRAD16") != "1":
             # an input gradient with 16 output channels would leave half of every 32-wide matrix block empty: the library's kernel
             dx = torch.ops.aten.convolution_backward(g, x, w, None, [1, 1], [pad, pad], [1, 1], False, [0, 0], 1,
                                                      [True, False, False])[0]

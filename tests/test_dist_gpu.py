@@ -170,6 +170,44 @@ def test_two_ranks_exchange_gradients_over_ipc_peer_memory(tmp_path, monkeypatch
     torch.testing.assert_close(e0["p1"], r0["p1"], rtol=1e-6, atol=1e-7)
 
 
+def _p2p_late_worker(rank, world, port, out_dir):
+    """Rank 1 arrives 4 s late at the first exchange; rank 0 waits at most 1 s per exchange."""
+    import time
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      AURPPO_DP_ALLREDUCE="p2p", AURPPO_P2P_TIMEOUT_S="1" if rank == 0 else "30")
+    from aur_ppo_amd import dist as D
+    from aur_ppo_amd import hip_ops as H
+    D.init_from_env(backend="gloo")
+    n = 5000
+    x = D.make_p2p_exchange(H, n, torch.device("cuda", 0))
+    step = torch.ones(1, device="cuda")                      # exchange number 1
+    g = torch.full((n,), float(rank + 1), device="cuda")
+    D.barrier()
+    if rank == 1:
+        time.sleep(4.0)
+    t0 = time.perf_counter()
+    x.allreduce_mean_(g, n, step, timeout_s=float(os.environ["AURPPO_P2P_TIMEOUT_S"]))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    status = x.status()
+    torch.save(dict(status=status, dt=dt, mean=float(g[0])), os.path.join(out_dir, f"late{rank}.pt"))
+    D.barrier()
+    x.close()
+    torch.distributed.destroy_process_group()
+
+
+def test_exchange_with_a_late_peer_times_out_instead_of_hanging(tmp_path, monkeypatch):
+    """The exchange kernel polls its peers' flags with a wall-clock bound: a peer that does not arrive must cost the waiting rank its
+    timeout, raise the sticky status (1 + the late rank), and let the grid drain -- not hang the GPU.  The late rank itself finds
+    rank 0's flag already raised and completes normally."""
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    mp.start_processes(_p2p_late_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    r0, r1 = torch.load(tmp_path / "late0.pt"), torch.load(tmp_path / "late1.pt")
+    assert r0["status"] == 2, r0                      # 1 + rank 1
+    assert 0.9 <= r0["dt"] <= 3.5, r0                 # waited its one second, not the peer's four
+    assert r1["status"] == 0 and r1["mean"] == 1.5, r1
+
+
 def _worker_updates(rank, world, port, out_dir, updates):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     os.environ.pop("AURPPO_DP_ALLREDUCE", None)
