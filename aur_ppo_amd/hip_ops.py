@@ -761,6 +761,7 @@ class _FirstBlock(torch.autograd.Function):
 
 
 CONV3X3_MIN_PIXELS = 131072
+CONV3X3_MIN_WGS = 512
 
 
 class _Conv3x3(torch.autograd.Function):
@@ -810,7 +811,9 @@ def conv3x3_ok(x, cin, cout, pad):
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == cin and cin % 16 == 0 and cout % 32 == 0
             and pad in (0, 1, 2)):
         return False
-    return x.shape[0] * (x.shape[2] + 2 * pad - 2) * (x.shape[3] + 2 * pad - 2) >= CONV3X3_MIN_PIXELS
+    pixels = x.shape[0] * (x.shape[2] + 2 * pad - 2) * (x.shape[3] + 2 * pad - 2)
+    # a workgroup takes 256 output pixels x 128 output channels: the launch needs a few hundred of them to fill 256 CUs
+    return pixels >= CONV3X3_MIN_PIXELS or ((pixels + 255) // 256) * ((cout + 127) // 128) >= CONV3X3_MIN_WGS
 
 
 def conv3x3_supported(x, conv):
