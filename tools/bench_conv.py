@@ -4,6 +4,9 @@ and 4096 (config 5's shard): forward and input gradient, ms per call and TFLOP/s
 import argparse, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from aur_ppo_amd import _lib
+if os.environ.get("AURPPO_LIB"):
+    _lib.LIB_PATH = os.environ["AURPPO_LIB"]
 from aur_ppo_amd import hip_ops as H
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=8192)
