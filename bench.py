@@ -386,9 +386,20 @@ def run_workload(args, rank, world, dev, envs_per_gpu, steps, warmup, with_probe
     dp = world > 1 or args.force_dp
     if dp:
         agent.first_grad_probe = []
+    if getattr(agent, "_p2p", None) is not None:
+        D.barrier()                      # the one-shot exchange polls its peers against a wall-clock bound: start the first update together
     returns, advantages = agent.advantages(next_obs, next_done)
     n0 = agent.update(returns, advantages)
     torch.cuda.synchronize()
+    if getattr(agent, "_p2p", None) is not None:
+        # a peer whose flag never arrived (peer memory not visible across these devices, a dead rank) has cost every exchange of this
+        # update its timeout and raised the sticky status: agree on it across ranks and give the arm up HERE, together -- not after
+        # warmup + steps more updates at 16 timeouts each
+        st = torch.tensor([agent._p2p.status()], device=dev, dtype=torch.int32)
+        if world > 1:
+            torch.distributed.all_reduce(st, op=torch.distributed.ReduceOp.MAX)
+        if int(st) != 0:
+            raise RuntimeError(f"one-shot exchange: a peer's flag timed out during the first update (status {int(st)}: 1 + the late rank)")
     first_grad = agent.first_grad_probe[0].cpu().numpy() if (dp and agent.first_grad_probe) else None
     agent.first_grad_probe = None
     gpu_first = None
@@ -560,6 +571,9 @@ def main():
     args = parse()
     if args.dp_allreduce:
         os.environ["AURPPO_DP_ALLREDUCE"] = args.dp_allreduce       # (before the ranks are spawned: they inherit it)
+    # the one-shot exchange's poll bound while benchmarking: 2 s (the ranks enter every update together here; the trainer's default
+    # of 10 s would turn a broken peer mapping into 16 x 10 s per update)
+    os.environ.setdefault("AURPPO_P2P_TIMEOUT_S", "2")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
     # stdout carries exactly ONE line, the JSON: anything a library prints there (RCCL announces its version on stdout when
