@@ -166,3 +166,17 @@ def test_robot_ppo_two_ranks_stop_on_the_reduced_kl_together(tmp_path, kl, expec
     assert r0["steps"] == r1["steps"] == expect
     assert torch.equal(r0["p"], r1["p"])
     assert abs(r0["kl"] - r1["kl"]) > 1e-6          # the local values differ; the decision used their mean
+
+
+def test_allreduce_choice_reads_the_environment(monkeypatch):
+    """AURPPO_DP_ALLREDUCE picks the gradient exchange of the MLP policy's bucket: the process group's all-reduce (default) or
+    the one-shot exchange over HIP-IPC peer memory; anything else is an error, not a silent default."""
+    from aur_ppo_amd import dist as D
+    monkeypatch.delenv("AURPPO_DP_ALLREDUCE", raising=False)
+    assert D.allreduce_choice() == "rccl"
+    monkeypatch.setenv("AURPPO_DP_ALLREDUCE", "P2P")
+    assert D.allreduce_choice() == "p2p"
+    monkeypatch.setenv("AURPPO_DP_ALLREDUCE", "ring")
+    import pytest
+    with pytest.raises(ValueError):
+        D.allreduce_choice()
