@@ -246,8 +246,10 @@ struct LinArgs {
     const float* x;                  // (M, K)
     const unsigned short* wop;       // [n-block][k-step][plane][lane][8]
     float* y;                        // (M, N)
+    const float* bias;               // (N,) or nullptr
     long long M;
     int K, N, n_mb;
+    int act;                         // 0: none, 1: tanh (1 - 2 / (e^{2x} + 1), as the fused MLP steps form it)
 };
 
 template <int NB>
@@ -342,10 +344,13 @@ __global__ __launch_bounds__(kConvThreads, 2) void k_linear(const LinArgs a) {
         for (int nb = 0; nb < NB; ++nb) {
             const int col = (ng * NB + nb) * 32 + (lane & 31);
             if (col < a.N) {
+                const float bv = a.bias ? a.bias[col] : 0.0f;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const long long r = m0[mb] + acc_row_c(e, lane);
-                    if (r < a.M) a.y[(size_t)r * a.N + col] = acc[mb][nb][e];
+                    float v = acc[mb][nb][e] + bv;
+                    if (a.act == 1) v = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * v) + 1.0f);
+                    if (r < a.M) a.y[(size_t)r * a.N + col] = v;
                 }
             }
         }
@@ -410,8 +415,24 @@ extern "C" int aurppo_conv3x3_f32(const float* x, const float* w, float* z, int 
 // mode 0: y (M, N_w) = x (M, K_w) . w (N_w, K_w)^T      -- nn.Linear without its bias; K_w a multiple of 16
 // mode 1: y (M, K_w) = x (M, N_w) . w (N_w, K_w)         -- the gradient with respect to the input (x is dY); N_w a multiple of 16
 // wop_ws: aurppo_conv3x3_wop_bytes(product's K, product's N) / 9 bytes suffice; the same function's size is accepted.
+static int linear_impl(const float* x, const float* w, const float* bias, int act, float* y, long long M, int K_w, int N_w, int mode,
+                       void* wop_ws, void* stream);
+
 extern "C" int aurppo_linear_f32(const float* x, const float* w, float* y, long long M, int K_w, int N_w, int mode, void* wop_ws,
                                  void* stream) {
+    return linear_impl(x, w, nullptr, 0, y, M, K_w, N_w, mode, wop_ws, stream);
+}
+
+// y (M, N_w) = act(x (M, K_w) . w (N_w, K_w)^T + bias): nn.Linear with its bias and, act = 1, the nn.Tanh behind it
+// (src/nets/nets.py:21-27: every hidden layer of the reference's MLPs) in the product's epilogue.
+extern "C" int aurppo_linear_bias_act_f32(const float* x, const float* w, const float* bias, float* y, long long M, int K_w, int N_w,
+                                          int act, void* wop_ws, void* stream) {
+    AURPPO_REQUIRE(act == 0 || act == 1, AURPPO_EINVAL, "aurppo_linear_bias_act_f32: act %d", act);
+    return linear_impl(x, w, bias, act, y, M, K_w, N_w, 0, wop_ws, stream);
+}
+
+static int linear_impl(const float* x, const float* w, const float* bias, int act, float* y, long long M, int K_w, int N_w, int mode,
+                       void* wop_ws, void* stream) {
     AURPPO_REQUIRE(x && w && y && wop_ws, AURPPO_EINVAL, "aurppo_linear_f32: null pointer");
     AURPPO_REQUIRE(mode == 0 || mode == 1, AURPPO_EINVAL, "aurppo_linear_f32: mode %d", mode);
     const int K = mode == 0 ? K_w : N_w, N = mode == 0 ? N_w : K_w;
@@ -425,6 +446,7 @@ extern "C" int aurppo_linear_f32(const float* x, const float* w, float* y, long 
     AURPPO_LAUNCH_CHECK("k_conv_prep");
     LinArgs a;
     a.x = x; a.wop = wop; a.y = y; a.M = M; a.K = K; a.N = N;
+    a.bias = bias; a.act = act;
     const long long n_mb = (M + 32 * 4 * kMB - 1) / (32 * 4 * kMB);
     const int nblk = (N + 31) / 32;
     const int NB = nblk >= 4 ? 4 : (nblk >= 2 ? 2 : 1);

@@ -853,6 +853,19 @@ def linear_nobias(x, w, mode=0):
     return y
 
 
+def linear_bias_act(x, w, bias, act=0):
+    """``act(x @ w.T + bias)`` in one kernel (act: 0 none, 1 tanh): csrc/conv.hip::k_linear with the layer's tail in its epilogue."""
+    lib = _lib_or_raise()
+    x, w = x.contiguous(), w.contiguous()
+    M = x.shape[0]
+    Nw, Kw = w.shape
+    y = torch.empty((M, Nw), dtype=torch.float32, device=x.device)
+    ws = _workspace("conv", lib.aurppo_conv3x3_wop_bytes(Kw, Nw), x.device)
+    _check(lib.aurppo_linear_bias_act_f32(_ptr(x), _ptr(w), _ptr(bias.contiguous()) if bias is not None else None, _ptr(y), M, Kw, Nw,
+                                          int(act), C.c_void_p(ws.data_ptr()), _stream()), "aurppo_linear_bias_act_f32")
+    return y
+
+
 def first_block(obs, state, weight, bias):
     """K10: ``max_pool2d(relu(conv2d(cat[obs, state tiled to a plane], weight, bias, padding=1)), 2)`` -- the first block of
     src/nets/base_cnns.py:28-31 on the input of src/models/robot_actor_critic.py:58-59 -- forward and backward without the

@@ -65,6 +65,57 @@ class _LinearSplitK(torch.autograd.Function):
         return gx, gw, gy.sum(0)
 
 
+class _LinearTanhFn(torch.autograd.Function):
+    """``tanh(x W^T + b)`` as ONE kernel forward (csrc/conv.hip::k_linear with bias + tanh in its epilogue) -- a hidden layer of
+    src/nets/nets.py:21-27 for the shapes the fused K7 / K7w steps do not cover; backward: tanh' from the saved output, the input
+    gradient on the same kernel (mode 1), the weight gradient with the split over the batch of ``_LinearSplitK``."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        from . import hip_ops as H
+        h = H.linear_bias_act(x.detach(), weight.detach(), bias.detach(), 1)
+        ctx.save_for_backward(x, weight, h)
+        return h
+
+    @staticmethod
+    def backward(ctx, gh):
+        from . import hip_ops as H
+        x, weight, h = ctx.saved_tensors
+        gz = torch.ops.aten.tanh_backward(gh.contiguous(), h)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = H.linear_nobias(gz, weight.detach(), 1) if H.linear_ok(gz, weight.shape[0], weight.shape[1]) else gz @ weight
+        m, s = x.shape[0], _LinearSplitK.SLABS
+        if m % s == 0 and m >= _LinearSplitK.MIN_ROWS:
+            gw = torch.bmm(gz.view(s, m // s, -1).transpose(1, 2), x.view(s, m // s, -1)).sum(0)
+        else:
+            gw = gz.t() @ x
+        return gx, gw, gz.sum(0)
+
+
+class _TanhMLP(nn.Sequential):
+    """``nn.Sequential`` of (Linear, Tanh)* + head with the reference's state-dict keys; on the GPU a (Linear, Tanh) pair whose
+    shape k_linear takes (hip_ops.linear_ok: inner width a multiple of 16, outer a multiple of 32, >= 32 768 rows) runs as one
+    fused kernel when ``AURPPO_LINEAR_BF16X3=1``."""
+
+    def forward(self, x):
+        mods = list(self)
+        i = 0
+        fuse = x.is_cuda and torch.is_grad_enabled() and os.environ.get("AURPPO_LINEAR_BF16X3") == "1"
+        if fuse:
+            from . import hip_ops as H
+        while i < len(mods):
+            m = mods[i]
+            if (fuse and isinstance(m, nn.Linear) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.Tanh) and x.dim() == 2
+                    and H.linear_ok(x, m.in_features, m.out_features)):
+                x = _LinearTanhFn.apply(x, m.weight, m.bias)
+                i += 2
+            else:
+                x = m(x)
+                i += 1
+        return x
+
+
 class _Linear(nn.Linear):
     """nn.Linear (same parameters / state-dict keys) with the split-batch weight gradient."""
 
@@ -87,7 +138,7 @@ def _tanh_mlp(input_dim, dim, output_dim, num_layers, head_std):
         mods += [layer_init(_Linear(width_in, dim)), nn.Tanh()]
         width_in = dim
     mods.append(layer_init(_Linear(dim, int(np.prod(output_dim))), head_std))
-    return nn.Sequential(*mods)
+    return _TanhMLP(*mods)
 
 
 class discrete_net(nn.Module):

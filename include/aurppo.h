@@ -263,6 +263,10 @@ int aurppo_conv3x3_f32(const float* x, const float* w, float* z, int B, int Ci_w
  * wop_ws: aurppo_conv3x3_wop_bytes(inner dimension, columns) bytes. */
 int aurppo_linear_f32(const float* x, const float* w, float* y, long long M, int K_w, int N_w, int mode, void* wop_ws,
                       void* stream);
+/* The forward product with the layer's bias (may be NULL) and, act = 1, the nn.Tanh that follows every hidden layer
+ * (src/nets/nets.py:21-27) in its epilogue: y = act(x . w^T + bias). */
+int aurppo_linear_bias_act_f32(const float* x, const float* w, const float* bias, float* y, long long M, int K_w, int N_w,
+                               int act, void* wop_ws, void* stream);
 
 /* ---- one-shot gradient all-reduce over peer memory (one process per GPU; SURVEY 8e plan B) ------------------
  * Where it sits in the reference: between loss.backward() and clip_grad_norm_ (src/ppo.py:266-268); upstream is

@@ -112,3 +112,24 @@ def test_linear_forward_and_input_gradient_match_the_fp64_product(M, K, N, monke
     torch.testing.assert_close(out, outr, rtol=2e-5, atol=2e-5)
     torch.testing.assert_close(xin.grad, xr.grad, rtol=2e-4, atol=2e-5 * float(xr.grad.abs().max()))
     torch.testing.assert_close(lin.weight.grad, ref.weight.grad, rtol=2e-4, atol=2e-5 * float(ref.weight.grad.abs().max()))
+
+
+def test_fused_linear_tanh_layer_matches_the_stock_modules(monkeypatch):
+    """nets._TanhMLP with AURPPO_LINEAR_BF16X3=1: (Linear, Tanh) pairs as one kernel -- outputs and every gradient against the same
+    Sequential on torch's modules (same parameters)."""
+    from aur_ppo_amd import nets
+    torch.manual_seed(3)
+    net = nets.continuous_net(256, (64,), (6,), 2, 0.0).cuda()
+    x = torch.randn(32768, 64, device="cuda")
+    outs = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("AURPPO_LINEAR_BF16X3", fused)
+        net.zero_grad()
+        xin = x.clone().requires_grad_(True)
+        y = net(xin)
+        (y.square().sum() / y.numel()).backward()
+        outs.append((y.detach().clone(), xin.grad.clone(), [p.grad.clone() for p in net.parameters()]))
+    torch.testing.assert_close(outs[0][0], outs[1][0], rtol=2e-5, atol=2e-6)
+    torch.testing.assert_close(outs[0][1], outs[1][1], rtol=2e-4, atol=2e-5 * float(outs[1][1].abs().max()))
+    for a, b in zip(outs[0][2], outs[1][2]):
+        torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-5 * float(b.abs().max()) + 1e-9)
