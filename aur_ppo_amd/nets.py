@@ -96,17 +96,21 @@ class _LinearTanhFn(torch.autograd.Function):
 class _TanhMLP(nn.Sequential):
     """``nn.Sequential`` of (Linear, Tanh)* + head with the reference's state-dict keys; on the GPU a (Linear, Tanh) pair whose
     shape k_linear takes (hip_ops.linear_ok: inner width a multiple of 16, outer a multiple of 32, >= 32 768 rows) runs as one
-    fused kernel when ``AURPPO_LINEAR_BF16X3=1``."""
+    fused kernel: by default for layers wider than 128 -- the shapes the fused K7 / K7w steps do not cover (bench.py --hidden-dim
+    256: 38.3 -> 36.8 ms per update with two layers, 58.7 -> 52.9 ms with three) -- and for every such pair with
+    ``AURPPO_LINEAR_BF16X3=1``; ``=0`` keeps torch's modules."""
 
     def forward(self, x):
         mods = list(self)
         i = 0
-        fuse = x.is_cuda and torch.is_grad_enabled() and os.environ.get("AURPPO_LINEAR_BF16X3") == "1"
+        env = os.environ.get("AURPPO_LINEAR_BF16X3", "")
+        fuse = x.is_cuda and torch.is_grad_enabled() and env != "0"
         if fuse:
             from . import hip_ops as H
         while i < len(mods):
             m = mods[i]
             if (fuse and isinstance(m, nn.Linear) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.Tanh) and x.dim() == 2
+                    and (env == "1" or max(m.in_features, m.out_features) > 128)
                     and H.linear_ok(x, m.in_features, m.out_features)):
                 x = _LinearTanhFn.apply(x, m.weight, m.bias)
                 i += 2
