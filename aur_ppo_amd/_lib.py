@@ -18,6 +18,7 @@ SYMBOLS = (
     "aurppo_p2p_get_handle", "aurppo_p2p_open_peers", "aurppo_p2p_allreduce_mean_f32", "aurppo_p2p_status", "aurppo_p2p_destroy", "aurppo_pack_records_f32", "aurppo_mlp_act_f32", "aurppo_clip_adam_f32",
     "aurppo_bias_relu_pool2_fwd_f32", "aurppo_bias_relu_pool2_bwd_f32", "aurppo_weighted_batch_sum_f32",
     "aurppo_first_block_fwd_f32", "aurppo_first_block_bwd_f32", "aurppo_conv3x3_wop_bytes", "aurppo_conv3x3_f32", "aurppo_linear_f32", "aurppo_linear_bias_act_f32",
+    "aurppo_linear_wgrad_ws_bytes", "aurppo_linear_wgrad_f32", "aurppo_conv3x3_wgrad_ws_bytes", "aurppo_conv3x3_wgrad_f32",
     "aurppo_mlp_wide_workspace_bytes", "aurppo_mlp_wide_ppo_step_f32", "aurppo_mlp_wide_ppo_minibatch_f32",
     "aurppo_mlp_wide_act_f32",
 )
@@ -100,13 +101,20 @@ def load() -> C.CDLL:
     lib.aurppo_conv3x3_f32.argtypes = [vp, vp, vp] + [i32] * 7 + [vp, vp]
     lib.aurppo_linear_f32.argtypes = [vp, vp, vp, C.c_longlong, i32, i32, i32, vp, vp]
     lib.aurppo_linear_bias_act_f32.argtypes = [vp, vp, vp, vp, C.c_longlong, i32, i32, i32, vp, vp]
+    lib.aurppo_linear_wgrad_ws_bytes.argtypes = [C.c_longlong, i32, i32]
+    lib.aurppo_linear_wgrad_ws_bytes.restype = C.c_size_t
+    lib.aurppo_linear_wgrad_f32.argtypes = [vp, vp, vp, C.c_longlong, i32, i32, vp, vp]
+    lib.aurppo_conv3x3_wgrad_ws_bytes.argtypes = [i32] * 6
+    lib.aurppo_conv3x3_wgrad_ws_bytes.restype = C.c_size_t
+    lib.aurppo_conv3x3_wgrad_f32.argtypes = [vp, vp, vp] + [i32] * 6 + [vp, vp]
     lib.aurppo_clip_workspace_bytes.argtypes = [C.c_int64]
     lib.aurppo_clip_workspace_bytes.restype = C.c_size_t
     lib.aurppo_grad_norm_clip_f32.argtypes = [vp, C.c_int64, f64, vp, vp, vp]
     for name in SYMBOLS:
         fn = getattr(lib, name)
         if name not in ("aurppo_last_error", "aurppo_loss_workspace_bytes", "aurppo_clip_workspace_bytes",
-                        "aurppo_mlp_workspace_bytes", "aurppo_conv3x3_wop_bytes"):
+                        "aurppo_mlp_workspace_bytes", "aurppo_conv3x3_wop_bytes", "aurppo_linear_wgrad_ws_bytes",
+                        "aurppo_conv3x3_wgrad_ws_bytes"):
             fn.restype = i32
     _lib = lib
     return lib

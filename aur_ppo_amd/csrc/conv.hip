@@ -356,6 +356,309 @@ __global__ __launch_bounds__(kConvThreads, 2) void k_linear(const LinArgs a) {
         }
 }
 
+// ---- nn.Linear's weight gradient on the same arithmetic: dW (N, K) = dY^T (N, M) . X (M, K), both operands row-major with the
+// minibatch's rows as the product's inner dimension.  Both operands change every k-step, so both are split; to split every
+// element once per WORKGROUP (not once per wave that uses it) the workgroup stages 32 rows of its 128 dY columns and its 128 X
+// columns as bf16-plane X images in LDS (bf16x3.h: 8-byte stores along a row, fragments by transposed reads across rows -- the
+// images k_mlp_step3 lands its observation rows in), and its four waves each form a 64 x 64 quarter of the 128 x 128 tile.
+// The inner dimension is cut into S slices: partial[s] (N, K) per slice, summed by the caller in fixed order (deterministic).
+struct WgradArgs {
+    const float* dy;                 // (M, N)
+    const float* x;                  // (M, K)
+    float* part;                     // (S, N, K)
+    long long M;
+    int N, K, rows_per_slice, n_tiles_n, n_tiles_k;
+};
+
+__global__ __launch_bounds__(kConvThreads, 2) void k_linear_wgrad(const WgradArgs a) {
+    __shared__ __attribute__((aligned(16))) char s_img[2 * 2 * 3 * kXPlane];      // [dY | X][64-column half][3 planes][32 rows x 128 B]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = (int)(blockIdx.x % (unsigned)(a.n_tiles_n * a.n_tiles_k)), s = (int)(blockIdx.x / (unsigned)(a.n_tiles_n * a.n_tiles_k));
+    const int n0 = (tile / a.n_tiles_k) * 128, k0 = (tile % a.n_tiles_k) * 128;
+    const long long m_lo = (long long)s * a.rows_per_slice;
+    long long m_hi = m_lo + a.rows_per_slice;
+    if (m_hi > a.M) m_hi = a.M;
+    char* const imgA = s_img;                               // dY columns n0 .. n0 + 127
+    char* const imgB = s_img + 2 * 3 * kXPlane;            // X columns k0 .. k0 + 127
+    const int wn = w >> 1, wk = w & 1;                      // this wave's 64 x 64 quarter
+    // staging: a chunk = 32 rows x 128 columns of each operand = 1024 float4 per operand, four per thread
+    const int r_of = tid >> 5, c4 = (tid & 31) * 4;         // + 8 rows per further slot
+    f32x16c acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    float pa[4][4], pb[4][4];
+    auto fetch = [&](long long m0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long r = m0 + r_of + 8 * u;
+            const bool okr = r < m_hi;
+            const bool oka = okr && n0 + c4 < a.N, okb = okr && k0 + c4 < a.K;      // (N and K are multiples of 4)
+            const float4 va = *reinterpret_cast<const float4*>(a.dy + (oka ? (size_t)r * a.N + n0 + c4 : (size_t)0));
+            const float4 vb = *reinterpret_cast<const float4*>(a.x + (okb ? (size_t)r * a.K + k0 + c4 : (size_t)0));
+            pa[u][0] = oka ? va.x : 0.0f; pa[u][1] = oka ? va.y : 0.0f; pa[u][2] = oka ? va.z : 0.0f; pa[u][3] = oka ? va.w : 0.0f;
+            pb[u][0] = okb ? vb.x : 0.0f; pb[u][1] = okb ? vb.y : 0.0f; pb[u][2] = okb ? vb.z : 0.0f; pb[u][3] = okb ? vb.w : 0.0f;
+        }
+    };
+    fetch(m_lo);
+    for (long long m0 = m_lo; m0 < m_hi; m0 += 32) {
+        __syncthreads();                                    // the previous chunk's fragments have been read
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = r_of + 8 * u;
+            store_x4(imgA + (c4 >> 6) * 3 * kXPlane, r, c4 & 63, pa[u][0], pa[u][1], pa[u][2], pa[u][3]);
+            store_x4(imgB + (c4 >> 6) * 3 * kXPlane, r, c4 & 63, pb[u][0], pb[u][1], pb[u][2], pb[u][3]);
+        }
+        __syncthreads();
+        if (m0 + 32 < m_hi) fetch(m0 + 32);                 // the next chunk's rows, behind this chunk's products
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const Frag3 A0 = x_cols(imgA + wn * 3 * kXPlane, ks, 0, lane), A1 = x_cols(imgA + wn * 3 * kXPlane, ks, 32, lane);
+            const Frag3 B0 = x_cols(imgB + wk * 3 * kXPlane, ks, 0, lane), B1 = x_cols(imgB + wk * 3 * kXPlane, ks, 32, lane);
+            acc[0][0] = mma32x3(A0, B0, acc[0][0]);
+            acc[0][1] = mma32x3(A0, B1, acc[0][1]);
+            acc[1][0] = mma32x3(A1, B0, acc[1][0]);
+            acc[1][1] = mma32x3(A1, B1, acc[1][1]);
+        }
+    }
+    // C[m = dY column][n = X column]: the lane holds the X column, its registers the dY columns -- rows of `part` are contiguous over the lanes
+    float* const out = a.part + (size_t)s * a.N * a.K;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = k0 + wk * 64 + j * 32 + (lane & 31);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = n0 + wn * 64 + i * 32 + acc_row_c(e, lane);
+                if (row < a.N && col < a.K) out[(size_t)row * a.K + col] = acc[i][j][e];
+            }
+        }
+}
+
+
+// ---- K12: the 3x3 convolution's WEIGHT gradient on the same arithmetic.
+//     dW[co][ci][ky][kx] = sum over (b, y, x) of dY[b][co][y][x] * X[b][ci][y + ky - p][x + kx - p]
+// as a product C[m = co][n = ci * 9 + tap] = A[m][k = pixel] . B[k = pixel][n] whose inner dimension is the batch's output pixels
+// (flattened) and whose output IS the filter's memory layout.  Both operands are new every k-step, so both are split: once per
+// WORKGROUP, through LDS.  In NCHW the inner dimension is the contiguous one of both operands (a channel's pixels), which is the
+// F image of bf16x3.h ([row = channel][32 samples], 8-byte stores of 4 consecutive samples, fragments by ds_read_b128 along a
+// row): one image holds the workgroup's dY channels (64 WM rows) and its (ci, tap) columns (64 (4 / WM) rows) for a chunk of
+// 32 pixels; each of the four waves forms a 64 x 64 part (2 x 2 accumulator blocks) of the tile.
+//   * a thread stages 4 consecutive pixels of 8 (10) rows; the pixels' offsets / tap masks of a chunk come from a 32-entry table
+//     that 32 lanes fill ahead of its use (two integer divisions per pixel, once per workgroup instead of once per row);
+//   * loads are buffer loads relative to the slice's first image (32-bit offsets whatever the tensor's size); a tap outside the
+//     image, a row past the tensor and a pixel past the slice get an offset past the buffer: the hardware returns 0.  QUAD (the
+//     map's width a multiple of 4, padding <= 1: a quad of output pixels never leaves its row): one 16-byte load per row and
+//     quad -- the X quad of a tap one column to the left starts at its second pixel and is shifted in registers;
+//   * the values of chunk c + 2 are requested while chunk c is multiplied (two register sets);
+//   * the pixels are cut into S slices (grid = tiles x S); k_fold_slices sums the partial filters in slice order (deterministic).
+struct ConvWgradArgs {
+    const float* dy;                 // (B, Co, Ho, Wo)
+    const float* x;                  // (B, Ci, H, W)
+    float* part;                     // (S, Co, Ci * 9)
+    int B, Ci, H, W, Co, Ho, Wo, pad;
+    long long M;                     // B * Ho * Wo
+    int NK;                          // Ci * 9
+    int px_per_slice;                // a multiple of 32
+    int n_tiles_m, n_tiles_n;
+};
+
+constexpr unsigned kOob = 0x80000000u;      // buffer offsets from here on read 0 (num_records <= 2^31)
+
+template <int PL>
+__device__ __forceinline__ Frag3 wg_rows(const char* img, int f0, int ks, int lane) {       // A[m = f0 + ..][k] / B[k][n = f0 + ..]
+    const int o = foff(f0 + (lane & 31), 16 * ks + 8 * (lane >> 5));
+    Frag3 f;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) f.p[p] = lds_b128(img + p * PL + o);
+    return f;
+}
+
+template <int WM, bool QUAD>      // WM waves along the output channels: tile = 64 WM channels x 64 (4 / WM) filter columns
+__global__ __launch_bounds__(kConvThreads, 2) void k_conv3x3_wgrad(const ConvWgradArgs a) {
+    constexpr int kRowsA = 64 * WM, kRowsB = 64 * (4 / WM), kSlotsA = 2 * WM, kSlots = (kRowsA + kRowsB) / 32;
+    constexpr int PL = (kRowsA + kRowsB) * kFRow;         // one bf16 plane of the image
+    __shared__ __attribute__((aligned(16))) char s_img[3 * PL];
+    __shared__ uint4 s_tab[3][32];                        // per pixel of a chunk: {dY offset, X offset, tap mask | valid << 9, -}
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles = a.n_tiles_m * a.n_tiles_n;
+    const int tile = (int)(blockIdx.x % (unsigned)tiles), s = (int)(blockIdx.x / (unsigned)tiles);
+    const int co0 = (tile / a.n_tiles_n) * kRowsA, n0 = (tile % a.n_tiles_n) * kRowsB;
+    const int HoWo = a.Ho * a.Wo, HW = a.H * a.W;
+    const long long m_lo = (long long)s * a.px_per_slice;
+    long long m_hi = m_lo + a.px_per_slice;
+    if (m_hi > a.M) m_hi = a.M;
+    const int n_px = (int)(m_hi - m_lo);
+    const int b_lo = (int)(m_lo / HoWo), r_lo = (int)(m_lo - (long long)b_lo * HoWo);
+    // buffers that start at the slice's first image
+    const size_t left_a = (size_t)(a.B - b_lo) * a.Co * HoWo * 4, left_b = (size_t)(a.B - b_lo) * a.Ci * HW * 4;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.dy + (size_t)b_lo * a.Co * HoWo), 0, (unsigned)(left_a < kOob ? left_a : kOob), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.x + (size_t)b_lo * a.Ci * HW), 0, (unsigned)(left_b < kOob ? left_b : kOob), 0x00020000);
+    // this thread's image rows (crow + 32 u) and its pixel quad
+    const int q4 = (tid & 7) * 4, crow = tid >> 3;
+    unsigned row_off[kSlots], row_bit[kSlots];
+#pragma unroll
+    for (int u = 0; u < kSlots; ++u) {
+        const int row = crow + 32 * u;
+        if (u < kSlotsA) {
+            const int co = co0 + row;
+            row_off[u] = (unsigned)co * (unsigned)HoWo * 4u;
+            row_bit[u] = co < a.Co ? (1u << 9) : 0u;
+        } else {
+            const int n = n0 + row - kRowsA;
+            const int ci = n / 9, tap = n - 9 * ci;
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            row_off[u] = (unsigned)((ci * HW + ky * a.W + kx) * 4);
+            row_bit[u] = n < a.NK ? (1u << tap) : 0u;
+        }
+    }
+    auto table = [&](int c) {
+        if (tid < 32) {
+            const int i = c * 32 + tid;
+            uint4 e = make_uint4(kOob, kOob, 0u, 0u);
+            if (i < n_px) {
+                const int mrel = r_lo + i;                       // relative to the first pixel of image b_lo
+                const int b = mrel / HoWo, r = mrel - b * HoWo;
+                const int y = r / a.Wo, x = r - y * a.Wo;
+                unsigned mask = 1u << 9;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int iy = y + t / 3 - a.pad, ix = x + t % 3 - a.pad;
+                    if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) mask |= 1u << t;
+                }
+                e.x = (unsigned)(b * a.Co * HoWo + r) * 4u;
+                e.y = (unsigned)(b * a.Ci * HW + (y - a.pad) * a.W + (x - a.pad)) * 4u;      // (may wrap: used with a valid tap only)
+                e.z = mask;
+            }
+            s_tab[c % 3][tid] = e;
+        }
+    };
+    auto fetch = [&](int c, float (&v)[kSlots][4]) {
+        const uint4* const tab = s_tab[c % 3];
+        if (QUAD) {
+            // the quad sits in one row of its image: pixel 1 is inside the image for every tap whose row is (W >= 4, pad <= 1);
+            // pixel 0 / pixel 3 may fall off the row's ends
+            const uint4 e0 = tab[q4], e1 = tab[q4 + 1], e3 = tab[q4 + 3];
+#pragma unroll
+            for (int u = 0; u < kSlots; ++u) {
+                if (u < kSlotsA) {
+                    const unsigned off = (e0.z & row_bit[u]) ? e0.x + row_off[u] : kOob;
+                    const u32x4 L = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, off, 0, 0));
+                    v[u][0] = __uint_as_float(L.x); v[u][1] = __uint_as_float(L.y);
+                    v[u][2] = __uint_as_float(L.z); v[u][3] = __uint_as_float(L.w);
+                } else {
+                    const bool on = (e1.z & row_bit[u]) != 0u;
+                    const bool shl = on && (e0.z & row_bit[u]) == 0u;            // pixel 0 is off the row: the load starts at pixel 1
+                    const bool m3 = (e3.z & row_bit[u]) != 0u;
+                    const unsigned off = on ? e1.y + row_off[u] - (shl ? 0u : 4u) : kOob;
+                    const u32x4 L = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, off, 0, 0));
+                    const float l0 = __uint_as_float(L.x), l1 = __uint_as_float(L.y), l2 = __uint_as_float(L.z), l3 = __uint_as_float(L.w);
+                    v[u][0] = shl ? 0.0f : l0;
+                    v[u][1] = shl ? l0 : l1;
+                    v[u][2] = shl ? l1 : l2;
+                    v[u][3] = shl ? l2 : (m3 ? l3 : 0.0f);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint4 e = tab[q4 + i];
+#pragma unroll
+                for (int u = 0; u < kSlots; ++u) {
+                    const bool on = (e.z & row_bit[u]) != 0u;
+                    const unsigned off = on ? (u < kSlotsA ? e.x : e.y) + row_off[u] : kOob;
+                    v[u][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(u < kSlotsA ? ra : rb, off, 0, 0));
+                }
+            }
+        }
+    };
+    const int wn = WM == 2 ? (w >> 1) : 0, wk = WM == 2 ? (w & 1) : w;
+    const int rowA = wn * 64, rowB = kRowsA + wk * 64;
+    f32x16c acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    const int n_chunks = (n_px + 31) >> 5;
+    // one chunk: its values (requested two chunks ago) -> planes -> products; meanwhile chunk c + 2 is requested into the same registers
+    auto step = [&](int c, float (&v)[kSlots][4]) {
+        __syncthreads();                                    // the previous chunk's fragments have been read; table c + 2 is written
+#pragma unroll
+        for (int u = 0; u < kSlots; ++u) {
+            unsigned a0, a1, a2, b0, b1, b2;
+            split3(v[u][0], v[u][1], a0, a1, a2);
+            split3(v[u][2], v[u][3], b0, b1, b2);
+            const int o = foff(crow + 32 * u, q4);
+            *reinterpret_cast<u32x2*>(s_img + 0 * PL + o) = u32x2{a0, b0};
+            *reinterpret_cast<u32x2*>(s_img + 1 * PL + o) = u32x2{a1, b1};
+            *reinterpret_cast<u32x2*>(s_img + 2 * PL + o) = u32x2{a2, b2};
+        }
+        __syncthreads();
+        if (c + 2 < n_chunks) fetch(c + 2, v);
+        if (c + 3 < n_chunks) table(c + 3);                 // (slot c % 3: last read by fetch(c), before this chunk's first barrier)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const Frag3 A0 = wg_rows<PL>(s_img, rowA, ks, lane), A1 = wg_rows<PL>(s_img, rowA + 32, ks, lane);
+            const Frag3 B0 = wg_rows<PL>(s_img, rowB, ks, lane), B1 = wg_rows<PL>(s_img, rowB + 32, ks, lane);
+            acc[0][0] = mma32x3(A0, B0, acc[0][0]);
+            acc[0][1] = mma32x3(A0, B1, acc[0][1]);
+            acc[1][0] = mma32x3(A1, B0, acc[1][0]);
+            acc[1][1] = mma32x3(A1, B1, acc[1][1]);
+        }
+    };
+    float va[kSlots][4], vb[kSlots][4];
+    table(0);
+    if (n_chunks > 1) table(1);
+    if (n_chunks > 2) table(2);
+    __syncthreads();
+    fetch(0, va);
+    if (n_chunks > 1) fetch(1, vb);
+    for (int c = 0; c < n_chunks; c += 2) {
+        step(c, va);
+        if (c + 1 < n_chunks) step(c + 1, vb);
+    }
+    // C[m = co][n]: the lane holds the filter column, its registers the channels -- rows of `part` are contiguous over the lanes
+    float* const out = a.part + (size_t)s * a.Co * a.NK;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wk * 64 + j * 32 + (lane & 31);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = co0 + rowA + i * 32 + acc_row_c(e, lane);
+                if (row < a.Co && col < a.NK) out[(size_t)row * a.NK + col] = acc[i][j][e];
+            }
+        }
+}
+
+// out[i] = part[0][i] + part[1][i] + ... in slice order; with `cols` > 0 also colsum[j] = the same sum over a (S, cols) array
+__global__ __launch_bounds__(256) void k_fold_slices(const float* __restrict__ part, int S, long long n, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float t = 0.0f;
+    int sl = 0;
+    for (; sl + 8 <= S; sl += 8) {
+        float x[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = part[(size_t)(sl + k) * n + i];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += x[k];
+    }
+    for (; sl < S; ++sl) t += part[(size_t)sl * n + i];
+    out[i] = t;
+}
+
 }  // namespace
 
 extern "C" size_t aurppo_conv3x3_wop_bytes(int cin_gemm, int cout_gemm) {
@@ -458,5 +761,118 @@ static int linear_impl(const float* x, const float* w, const float* bias, int ac
     else if (NB == 2) hipLaunchKernelGGL(k_linear<2>, g, blk, 0, s, a);
     else hipLaunchKernelGGL(k_linear<1>, g, blk, 0, s, a);
     AURPPO_LAUNCH_CHECK("k_linear");
+    return AURPPO_OK;
+}
+
+// ---- weight gradients: the inner dimension (the minibatch's rows / the batch's output pixels) is cut into S slices, the slices'
+// partial results land in the caller's workspace and k_fold_slices sums them in slice order.
+static int linear_wgrad_slices(long long M, int N, int K) {
+    const long long tiles = (long long)((N + 127) / 128) * ((K + 127) / 128);
+    long long s = (1024 + tiles - 1) / tiles;                 // about 1024 workgroups
+    const long long most = (M + 255) / 256;                   // at least 8 chunks of 32 rows per slice
+    if (s > most) s = most;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+extern "C" size_t aurppo_linear_wgrad_ws_bytes(long long M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    return (size_t)linear_wgrad_slices(M, N, K) * (size_t)N * (size_t)K * sizeof(float) + 64;
+}
+// dw (N, K) = dy (M, N)^T . x (M, K): nn.Linear's weight gradient (row-major fp32; N and K multiples of 4, 16-byte aligned operands)
+extern "C" int aurppo_linear_wgrad_f32(const float* dy, const float* x, float* dw, long long M, int N, int K, void* ws, void* stream) {
+    AURPPO_REQUIRE(dy && x && dw && ws, AURPPO_EINVAL, "aurppo_linear_wgrad_f32: null pointer");
+    AURPPO_REQUIRE(M > 0 && N > 0 && K > 0 && N % 4 == 0 && K % 4 == 0, AURPPO_ESHAPE,
+                   "aurppo_linear_wgrad_f32: M=%lld N=%d K=%d (N, K multiples of 4)", M, N, K);
+    AURPPO_REQUIRE(aligned_to(dy, 16) && aligned_to(x, 16) && aligned_to(ws, 16), AURPPO_EINVAL,
+                   "aurppo_linear_wgrad_f32: operands / workspace not 16-byte aligned");
+    const int S0 = linear_wgrad_slices(M, N, K);
+    WgradArgs a;
+    a.dy = dy; a.x = x; a.part = reinterpret_cast<float*>(ws); a.M = M; a.N = N; a.K = K;
+    const long long rps = ((M + S0 - 1) / S0 + 31) / 32 * 32;           // whole 32-row chunks per slice
+    const long long S = (M + rps - 1) / rps;
+    AURPPO_REQUIRE(S >= 1 && S <= S0 && rps < (1ll << 30), AURPPO_ESHAPE, "aurppo_linear_wgrad_f32: slice size");
+    a.rows_per_slice = (int)rps;
+    a.n_tiles_n = (N + 127) / 128;
+    a.n_tiles_k = (K + 127) / 128;
+    const long long grid = (long long)a.n_tiles_n * a.n_tiles_k * S;
+    AURPPO_REQUIRE(grid < (1ll << 31), AURPPO_ESHAPE, "aurppo_linear_wgrad_f32: grid too large");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_linear_wgrad, dim3((unsigned)grid), dim3(kConvThreads), 0, st, a);
+    AURPPO_LAUNCH_CHECK("k_linear_wgrad");
+    const long long n = (long long)N * K;
+    hipLaunchKernelGGL(k_fold_slices, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a.part, (int)S, n, dw);
+    AURPPO_LAUNCH_CHECK("k_fold_slices");
+    return AURPPO_OK;
+}
+
+// K12: dw (Co, Ci, 3, 3) = the gradient of conv2d(x (B, Ci, H, W), w, padding = pad) with respect to w, given the output gradient
+// dy (B, Co, H + 2 pad - 2, W + 2 pad - 2).  NCHW fp32.
+namespace {
+struct ConvWgradPlan {
+    int WM, n_tiles_m, n_tiles_n, S, px_per_slice;
+};
+bool conv_wgrad_plan(int B, int Ci, int Co, int H, int W, int pad, ConvWgradPlan* p) {
+    const int Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
+    if (B <= 0 || Ci <= 0 || Co <= 0 || Ho <= 0 || Wo <= 0 || pad < 0 || pad > 2) return false;
+    const long long M = (long long)B * Ho * Wo, HoWo = (long long)Ho * Wo, HW = (long long)H * W;
+    const int NK = Ci * 9;
+    p->WM = Co > 64 ? 2 : 1;
+    p->n_tiles_m = (Co + 64 * p->WM - 1) / (64 * p->WM);
+    p->n_tiles_n = (NK + 64 * (4 / p->WM) - 1) / (64 * (4 / p->WM));
+    const long long tiles = (long long)p->n_tiles_m * p->n_tiles_n;
+    long long S = (1024 + tiles - 1) / tiles;
+    const long long most = (M + 511) / 512;                  // at least 16 chunks of 32 pixels per slice
+    if (S > most) S = most;
+    if (S < 1) S = 1;
+    long long pps = ((M + S - 1) / S + 31) / 32 * 32;
+    // 32-bit offsets relative to the slice's first image: the images a slice touches must span less than 2^31 bytes of either tensor
+    const long long per_img = 4 * (HoWo * Co > HW * Ci ? HoWo * Co : HW * Ci);
+    if (per_img * 2 >= (1ll << 31)) return false;
+    while (pps > 32 && (pps / HoWo + 2) * per_img >= (1ll << 31)) pps = (pps / 2 + 31) / 32 * 32;
+    if ((pps / HoWo + 2) * per_img >= (1ll << 31)) return false;
+    S = (M + pps - 1) / pps;
+    if (S * tiles >= (1ll << 31) || S > (1 << 20)) return false;
+    p->S = (int)S;
+    p->px_per_slice = (int)pps;
+    return true;
+}
+}  // namespace
+
+extern "C" size_t aurppo_conv3x3_wgrad_ws_bytes(int B, int Ci, int Co, int H, int W, int pad) {
+    ConvWgradPlan p;
+    if (!conv_wgrad_plan(B, Ci, Co, H, W, pad, &p)) return 0;
+    return (size_t)p.S * (size_t)Co * (size_t)Ci * 9 * sizeof(float) + 64;
+}
+
+extern "C" int aurppo_conv3x3_wgrad_f32(const float* dy, const float* x, float* dw, int B, int Ci, int Co, int H, int W, int pad,
+                                        void* ws, void* stream) {
+    AURPPO_REQUIRE(dy && x && dw && ws, AURPPO_EINVAL, "aurppo_conv3x3_wgrad_f32: null pointer");
+    ConvWgradPlan p;
+    AURPPO_REQUIRE(conv_wgrad_plan(B, Ci, Co, H, W, pad, &p), AURPPO_ESHAPE,
+                   "aurppo_conv3x3_wgrad_f32: B=%d Ci=%d Co=%d H=%d W=%d pad=%d (pad 0..2, non-empty output, one image of either tensor "
+                   "under 1 GB)", B, Ci, Co, H, W, pad);
+    AURPPO_REQUIRE(aligned_to(ws, 16), AURPPO_EINVAL, "aurppo_conv3x3_wgrad_f32: workspace not 16-byte aligned");
+    ConvWgradArgs a;
+    a.dy = dy; a.x = x; a.part = reinterpret_cast<float*>(ws);
+    a.B = B; a.Ci = Ci; a.H = H; a.W = W; a.Co = Co; a.Ho = H + 2 * pad - 2; a.Wo = W + 2 * pad - 2; a.pad = pad;
+    a.M = (long long)B * a.Ho * a.Wo;
+    a.NK = Ci * 9;
+    a.px_per_slice = p.px_per_slice;
+    a.n_tiles_m = p.n_tiles_m; a.n_tiles_n = p.n_tiles_n;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 g((unsigned)((long long)p.n_tiles_m * p.n_tiles_n * p.S)), blk(kConvThreads);
+    // a quad of output pixels stays inside one row of its image, whose 16-byte pieces are aligned
+    const bool quad = a.Wo % 4 == 0 && W >= 4 && pad <= 1 && aligned_to(dy, 16) && getenv("AURPPO_K12_NOQUAD") == nullptr;
+    if (p.WM == 2) {
+        if (quad) hipLaunchKernelGGL((k_conv3x3_wgrad<2, true>), g, blk, 0, st, a);
+        else hipLaunchKernelGGL((k_conv3x3_wgrad<2, false>), g, blk, 0, st, a);
+    } else {
+        if (quad) hipLaunchKernelGGL((k_conv3x3_wgrad<1, true>), g, blk, 0, st, a);
+        else hipLaunchKernelGGL((k_conv3x3_wgrad<1, false>), g, blk, 0, st, a);
+    }
+    AURPPO_LAUNCH_CHECK("k_conv3x3_wgrad");
+    const long long n = (long long)Co * a.NK;
+    hipLaunchKernelGGL(k_fold_slices, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a.part, p.S, n, dw);
+    AURPPO_LAUNCH_CHECK("k_fold_slices");
     return AURPPO_OK;
 }

@@ -797,10 +797,48 @@ class _Conv3x3(torch.autograd.Function):
             _check(lib.aurppo_conv3x3_f32(_ptr(g), _ptr(w.detach()), _ptr(dx), B, Ci, Co, g.shape[2], g.shape[3], pad, 1,
                                           C.c_void_p(ws.data_ptr()), _stream()), "aurppo_conv3x3_f32")
         if ctx.needs_input_grad[1]:
-            # the weight gradient stays with the library's implicit-GEMM kernels (fp32 MFMAs at 50-80 % of their pipe)
-            dw = torch.ops.aten.convolution_backward(g, x, w, None, [1, 1], [pad, pad], [1, 1], False, [0, 0], 1,
-                                                     [False, True, False])[1]
+            if conv3x3_wgrad_ok(x, Ci, Co, pad):
+                dw = conv3x3_wgrad(g, x, Co, pad)       # K12
+            else:
+                # small channel counts would leave most of K12's 128 x 128 tile empty: the library's implicit-GEMM kernels
+                dw = torch.ops.aten.convolution_backward(g, x, w, None, [1, 1], [pad, pad], [1, 1], False, [0, 0], 1,
+                                                         [False, True, False])[1]
         return dx, dw, None
+
+
+def conv3x3_wgrad_ok(x, cin, cout, pad):
+    """K12's shape rule: the product's tile is 128 (64 for cout <= 64) output channels x 128 (192) filter columns (cin * 9), and
+    the layers below 64 output channels / 32 input channels leave most of it empty (the library's small-tile kernels win there).
+    ``AURPPO_NO_K12=1`` switches it off, ``AURPPO_K12_ALL=1`` takes every shape the kernel accepts (tests)."""
+    env = os.environ
+    if env.get("AURPPO_NO_K12") == "1" or not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and pad in (0, 1, 2)):
+        return False
+    if _lib_or_raise().aurppo_conv3x3_wgrad_ws_bytes(x.shape[0], cin, cout, x.shape[2], x.shape[3], pad) == 0:
+        return False
+    if env.get("AURPPO_K12_ALL") == "1":
+        return True
+    pixels = x.shape[0] * (x.shape[2] + 2 * pad - 2) * (x.shape[3] + 2 * pad - 2)
+    return cout >= K12_MIN_COUT and cin >= K12_MIN_CIN and pixels >= K12_MIN_PIXELS
+
+
+K12_MIN_COUT, K12_MIN_CIN, K12_MIN_PIXELS = 64, 32, 16384
+
+
+def conv3x3_wgrad(g, x, cout, pad):
+    """K12: the gradient of ``conv2d(x, w (cout, cin, 3, 3), padding=pad)`` with respect to ``w`` given the output gradient ``g``
+    (csrc/conv.hip::k_conv3x3_wgrad: a product over the batch's output pixels, both operands split once per workgroup)."""
+    lib = _lib_or_raise()
+    g, x = g.contiguous(), x.contiguous()
+    B, Ci, Hh, Ww = x.shape
+    assert g.shape == (B, cout, Hh + 2 * pad - 2, Ww + 2 * pad - 2), (g.shape, x.shape, cout, pad)
+    nb = lib.aurppo_conv3x3_wgrad_ws_bytes(B, Ci, cout, Hh, Ww, int(pad))
+    if nb == 0:
+        raise RuntimeError("aur_ppo_amd: aurppo_conv3x3_wgrad_f32 does not take this shape")
+    ws = _workspace("wgrad", nb, x.device)
+    dw = torch.empty((cout, Ci, 3, 3), dtype=torch.float32, device=x.device)
+    _check(lib.aurppo_conv3x3_wgrad_f32(_ptr(g), _ptr(x.detach()), _ptr(dw), B, Ci, cout, Hh, Ww, int(pad), C.c_void_p(ws.data_ptr()),
+                                        _stream()), "aurppo_conv3x3_wgrad_f32")
+    return dw
 
 
 def conv3x3_ok(x, cin, cout, pad):
@@ -851,6 +889,25 @@ def linear_nobias(x, w, mode=0):
     _check(lib.aurppo_linear_f32(_ptr(x), _ptr(w), _ptr(y), M, Kw, Nw, int(mode), C.c_void_p(ws.data_ptr()), _stream()),
            "aurppo_linear_f32")
     return y
+
+
+def linear_wgrad(gy, x):
+    """``gy.T @ x`` -- nn.Linear's weight gradient -- on the bf16 matrix pipe (csrc/conv.hip::k_linear_wgrad: both operands split
+    once per workgroup through LDS, the rows cut into slices that are summed in slice order)."""
+    lib = _lib_or_raise()
+    gy, x = gy.contiguous(), x.contiguous()
+    M, N = gy.shape
+    K = x.shape[1]
+    ws = _workspace("wgrad", lib.aurppo_linear_wgrad_ws_bytes(M, N, K), x.device)
+    dw = torch.empty((N, K), dtype=torch.float32, device=x.device)
+    _check(lib.aurppo_linear_wgrad_f32(_ptr(gy), _ptr(x.detach()), _ptr(dw), M, N, K, C.c_void_p(ws.data_ptr()), _stream()),
+           "aurppo_linear_wgrad_f32")
+    return dw
+
+
+def linear_wgrad_ok(gy, x):
+    return (gy.is_cuda and gy.dtype == torch.float32 and gy.dim() == 2 and x.dim() == 2 and gy.shape[1] % 4 == 0 and x.shape[1] % 4 == 0
+            and gy.shape[0] >= LINEAR_MIN_ROWS and gy.shape[1] >= 64 and x.shape[1] >= 64)
 
 
 def linear_bias_act(x, w, bias, act=0):

@@ -251,8 +251,7 @@ int aurppo_mlp_ppo_apply_parts_f32(float* params, float* grads, float* exp_avg, 
  * mode 1: the gradient with respect to the input: x is the OUTPUT gradient (B, Co, H, W), z the input gradient
  * (B, Ci, H + 2 - 2 pad, W + 2 - 2 pad), w the same (Co, Ci, 3, 3) filter, pad the forward padding.  The product's input
  * channel count (Ci in mode 0, Co in mode 1) must be a multiple of 16.  wop_ws: aurppo_conv3x3_wop_bytes(input channels,
- * output channels of the product) bytes of scratch for the filter in operand order.  (The weight gradient stays with the
- * library's implicit-GEMM kernels, which run fp32 MFMAs at 50-80 % of their pipe.) */
+ * output channels of the product) bytes of scratch for the filter in operand order.  (The weight gradient: aurppo_conv3x3_wgrad_f32.) */
 size_t aurppo_conv3x3_wop_bytes(int cin_gemm, int cout_gemm);
 int aurppo_conv3x3_f32(const float* x, const float* w, float* z, int B, int Ci_w, int Co_w, int H, int W, int pad, int mode,
                        void* wop_ws, void* stream);
@@ -267,6 +266,21 @@ int aurppo_linear_f32(const float* x, const float* w, float* y, long long M, int
  * (src/nets/nets.py:21-27) in its epilogue: y = act(x . w^T + bias). */
 int aurppo_linear_bias_act_f32(const float* x, const float* w, const float* bias, float* y, long long M, int K_w, int N_w,
                                int act, void* wop_ws, void* stream);
+/* nn.Linear's weight gradient on the same arithmetic: dw (N, K) = dy (M, N)^T . x (M, K) (what loss.backward() leaves in
+ * <layer>.weight.grad, src/ppo.py:266).  Both operands are split once per workgroup through LDS; the minibatch's rows are cut
+ * into slices whose partial products are summed in slice order (deterministic).  N, K multiples of 4; ws:
+ * aurppo_linear_wgrad_ws_bytes(M, N, K) bytes. */
+size_t aurppo_linear_wgrad_ws_bytes(long long M, int N, int K);
+int aurppo_linear_wgrad_f32(const float* dy, const float* x, float* dw, long long M, int N, int K, void* ws, void* stream);
+
+/* K12 -- the weight gradient of the 3x3 convolution of aurppo_conv3x3_f32 (src/nets/base_cnns.py:32-45, src/nets/equiv.py:12-62;
+ * what loss.backward() leaves in <conv>.weight.grad, src/robot_ppo.py:389): dw (Co, Ci, 3, 3) from x (B, Ci, H, W) and the
+ * output gradient dy (B, Co, H + 2 pad - 2, W + 2 pad - 2), NCHW fp32, as a product over the batch's output pixels on bf16 MFMAs
+ * over three-way splits (fp32-equivalent).  ws: aurppo_conv3x3_wgrad_ws_bytes(...) bytes (0 = shape not supported: pad outside
+ * 0..2, an empty output, or one image of either tensor of 1 GB and more). */
+size_t aurppo_conv3x3_wgrad_ws_bytes(int B, int Ci, int Co, int H, int W, int pad);
+int aurppo_conv3x3_wgrad_f32(const float* dy, const float* x, float* dw, int B, int Ci, int Co, int H, int W, int pad, void* ws,
+                             void* stream);
 
 /* ---- one-shot gradient all-reduce over peer memory (one process per GPU; SURVEY 8e plan B) ------------------
  * Where it sits in the reference: between loss.backward() and clip_grad_norm_ (src/ppo.py:266-268); upstream is

@@ -46,6 +46,56 @@ def test_conv3x3_forward_and_gradients_match_the_fp64_convolution(B, Ci, Co, H, 
     np.testing.assert_allclose(w.grad.cpu().numpy(), wd.grad.float().cpu().numpy(), rtol=2e-4, atol=2e-5 * float(wd.grad.abs().max()))
 
 
+# K12: batches large enough for several slices of pixels, slices that begin inside an image, maps whose size is not a multiple of
+# 4 (pixel quads that straddle rows and images), channel counts that do not fill the 128 x 128 tile, the 64-channel tile shape
+WGRAD_SHAPES = SHAPES + [(64, 64, 128, 16, 16, 1), (48, 32, 64, 21, 21, 1), (33, 128, 256, 5, 5, 0), (40, 64, 64, 10, 10, 1),
+                         (16, 32, 160, 13, 11, 2), (256, 256, 256, 8, 8, 0)]
+
+
+@pytest.mark.parametrize("B,Ci,Co,H,W,pad", WGRAD_SHAPES)
+def test_conv3x3_weight_gradient_matches_the_fp64_convolution(B, Ci, Co, H, W, pad, monkeypatch):
+    """K12 (csrc/conv.hip::k_conv3x3_wgrad) against the fp64 weight gradient, at the fp32 rounding level of the sum of |products|
+    behind a filter element; and through the autograd node of ``conv3x3`` (AURPPO_K12_ALL=1: every shape takes K12)."""
+    from aur_ppo_amd import hip_ops as Hh
+    g = torch.Generator(device="cuda").manual_seed(B * 977 + Ci + 3 * Co + H)
+    x = torch.randn(B, Ci, H, W, device="cuda", generator=g)
+    gz = torch.randn(B, Co, H + 2 * pad - 2, W + 2 * pad - 2, device="cuda", generator=g)
+    dw = Hh.conv3x3_wgrad(gz, x, Co, pad)
+    assert dw.shape == (Co, Ci, 3, 3)
+
+    def wgrad64(xx, gg):
+        wd = torch.zeros(Co, Ci, 3, 3, device="cuda", dtype=torch.float64, requires_grad=True)
+        torch.nn.functional.conv2d(xx.double(), wd, None, padding=pad).backward(gg.double())
+        return wd.grad
+    ref, mag = wgrad64(x, gz), wgrad64(x.abs(), gz.abs())
+    err = ((dw.double() - ref).abs() / mag.clamp_min(1e-30)).max().item()
+    assert err <= 1e-6, f"weight gradient: {err:.3e} of sum|ab|"
+    # the same through autograd, next to the forward pass and the input gradient
+    monkeypatch.setenv("AURPPO_K12_ALL", "1")
+    if Ci % 16 == 0:
+        xin = x.clone().requires_grad_(True)
+        w = (torch.randn(Co, Ci, 3, 3, device="cuda", generator=g) * (2.0 / (9 * Ci)) ** 0.5).requires_grad_(True)
+        Hh.conv3x3(xin, w, pad).backward(gz)
+        assert torch.equal(w.grad, dw)
+    # determinism: the slices are summed in slice order
+    assert torch.equal(Hh.conv3x3_wgrad(gz, x, Co, pad), dw)
+
+
+@pytest.mark.parametrize("M,N,K", [(32768, 256, 256), (40001, 256, 64), (33000, 96, 256), (70001, 160, 48), (32768, 64, 64), (1000, 256, 256)])
+def test_linear_weight_gradient_matches_the_fp64_product(M, N, K):
+    """csrc/conv.hip::k_linear_wgrad (dW = dY^T X for the layers wider than the fused steps cover) against fp64."""
+    from aur_ppo_amd import hip_ops as Hh
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    gy = torch.randn(M, N, device="cuda", generator=g)
+    x = torch.randn(M, K, device="cuda", generator=g)
+    dw = Hh.linear_wgrad(gy, x)
+    ref = gy.double().t() @ x.double()
+    mag = gy.abs().double().t() @ x.abs().double()
+    err = ((dw.double() - ref).abs() / mag).max().item()
+    assert err <= 1e-6, f"{err:.3e} of sum|ab|"
+    assert torch.equal(Hh.linear_wgrad(gy, x), dw)
+
+
 def test_conv3x3_equals_torch_conv2d_to_2e5_on_encoder_data():
     """The tolerance K10 is held to (2e-5 against torch's own fp32 convolution), at a hidden block's shape."""
     from aur_ppo_amd import hip_ops as Hh
