@@ -484,7 +484,9 @@ __global__ __launch_bounds__(kConvThreads, 2) void k_conv3x3_wgrad(const ConvWgr
     constexpr int kRowsA = 64 * WM, kRowsB = 64 * (4 / WM), kSlotsA = 2 * WM, kSlots = (kRowsA + kRowsB) / 32;
     constexpr int PL = (kRowsA + kRowsB) * kFRow;         // one bf16 plane of the image
     __shared__ __attribute__((aligned(16))) char s_img[3 * PL];
-    __shared__ uint4 s_tab[3][32];                        // per pixel of a chunk: {dY offset, X offset, tap mask | valid << 9, -}
+    // per chunk (three in flight): row 0 = the dY offsets of its 32 pixels, rows 1..9 = the X offsets per tap (the tap's shift
+    // included); a pixel past the slice / a tap outside the image holds kOob
+    __shared__ __attribute__((aligned(16))) unsigned s_tab[3][10][32];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles = a.n_tiles_m * a.n_tiles_n;
@@ -504,79 +506,75 @@ __global__ __launch_bounds__(kConvThreads, 2) void k_conv3x3_wgrad(const ConvWgr
         const_cast<float*>(a.x + (size_t)b_lo * a.Ci * HW), 0, (unsigned)(left_b < kOob ? left_b : kOob), 0x00020000);
     // this thread's image rows (crow + 32 u) and its pixel quad
     const int q4 = (tid & 7) * 4, crow = tid >> 3;
-    unsigned row_off[kSlots], row_bit[kSlots];
+    // rows past the tensor (channels >= Co, filter columns >= Ci * 9) are staged from wherever offset 0 + ... lands or from beyond
+    // the buffer: their products are never stored
+    unsigned row_off[kSlots];
+    int row_tap[kSlots];
 #pragma unroll
     for (int u = 0; u < kSlots; ++u) {
         const int row = crow + 32 * u;
         if (u < kSlotsA) {
             const int co = co0 + row;
-            row_off[u] = (unsigned)co * (unsigned)HoWo * 4u;
-            row_bit[u] = co < a.Co ? (1u << 9) : 0u;
+            row_off[u] = co < a.Co ? (unsigned)co * (unsigned)HoWo * 4u : kOob;
+            row_tap[u] = 0;
         } else {
             const int n = n0 + row - kRowsA;
-            const int ci = n / 9, tap = n - 9 * ci;
-            const int ky = tap / 3, kx = tap - 3 * ky;
-            row_off[u] = (unsigned)((ci * HW + ky * a.W + kx) * 4);
-            row_bit[u] = n < a.NK ? (1u << tap) : 0u;
+            const int ci = n / 9;
+            row_off[u] = n < a.NK ? (unsigned)(ci * HW) * 4u : kOob;
+            row_tap[u] = 1 + (n - 9 * ci);
         }
     }
     auto table = [&](int c) {
         if (tid < 32) {
             const int i = c * 32 + tid;
-            uint4 e = make_uint4(kOob, kOob, 0u, 0u);
+            unsigned (*const tab)[32] = s_tab[c % 3];
             if (i < n_px) {
                 const int mrel = r_lo + i;                       // relative to the first pixel of image b_lo
                 const int b = mrel / HoWo, r = mrel - b * HoWo;
                 const int y = r / a.Wo, x = r - y * a.Wo;
-                unsigned mask = 1u << 9;
+                tab[0][tid] = (unsigned)(b * a.Co * HoWo + r) * 4u;
+                const int base = b * a.Ci * HW + (y - a.pad) * a.W + (x - a.pad);
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
                     const int iy = y + t / 3 - a.pad, ix = x + t % 3 - a.pad;
-                    if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) mask |= 1u << t;
+                    const bool in = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+                    tab[1 + t][tid] = in ? (unsigned)(base + (t / 3) * a.W + t % 3) * 4u : kOob;
                 }
-                e.x = (unsigned)(b * a.Co * HoWo + r) * 4u;
-                e.y = (unsigned)(b * a.Ci * HW + (y - a.pad) * a.W + (x - a.pad)) * 4u;      // (may wrap: used with a valid tap only)
-                e.z = mask;
+            } else {
+#pragma unroll
+                for (int t = 0; t < 10; ++t) tab[t][tid] = kOob;
             }
-            s_tab[c % 3][tid] = e;
         }
     };
     auto fetch = [&](int c, float (&v)[kSlots][4]) {
-        const uint4* const tab = s_tab[c % 3];
-        if (QUAD) {
-            // the quad sits in one row of its image: pixel 1 is inside the image for every tap whose row is (W >= 4, pad <= 1);
-            // pixel 0 / pixel 3 may fall off the row's ends
-            const uint4 e0 = tab[q4], e1 = tab[q4 + 1], e3 = tab[q4 + 3];
+        const unsigned (*const tab)[32] = s_tab[c % 3];
 #pragma unroll
-            for (int u = 0; u < kSlots; ++u) {
+        for (int u = 0; u < kSlots; ++u) {
+            const u32x4 t = *reinterpret_cast<const u32x4*>(&tab[row_tap[u]][q4]);        // this row's offsets of the quad's pixels
+            if (QUAD) {
+                // the quad sits in one row of its image: pixel 1 is inside the image for every tap whose row is (W >= 4, pad <= 1);
+                // pixel 0 / pixel 3 may fall off the row's ends
+                u32x4 L;
                 if (u < kSlotsA) {
-                    const unsigned off = (e0.z & row_bit[u]) ? e0.x + row_off[u] : kOob;
-                    const u32x4 L = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, off, 0, 0));
+                    L = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, t.x + row_off[u], 0, 0));
                     v[u][0] = __uint_as_float(L.x); v[u][1] = __uint_as_float(L.y);
                     v[u][2] = __uint_as_float(L.z); v[u][3] = __uint_as_float(L.w);
                 } else {
-                    const bool on = (e1.z & row_bit[u]) != 0u;
-                    const bool shl = on && (e0.z & row_bit[u]) == 0u;            // pixel 0 is off the row: the load starts at pixel 1
-                    const bool m3 = (e3.z & row_bit[u]) != 0u;
-                    const unsigned off = on ? e1.y + row_off[u] - (shl ? 0u : 4u) : kOob;
-                    const u32x4 L = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, off, 0, 0));
+                    const bool shl = t.x >= kOob;                 // pixel 0 is off the row: the load starts at pixel 1
+                    const unsigned off = t.y < kOob ? (shl ? t.y : t.y - 4u) : kOob;
+                    L = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, off + row_off[u], 0, 0));
                     const float l0 = __uint_as_float(L.x), l1 = __uint_as_float(L.y), l2 = __uint_as_float(L.z), l3 = __uint_as_float(L.w);
                     v[u][0] = shl ? 0.0f : l0;
                     v[u][1] = shl ? l0 : l1;
                     v[u][2] = shl ? l1 : l2;
-                    v[u][3] = shl ? l2 : (m3 ? l3 : 0.0f);
+                    v[u][3] = shl ? l2 : (t.w < kOob ? l3 : 0.0f);
                 }
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint4 e = tab[q4 + i];
-#pragma unroll
-                for (int u = 0; u < kSlots; ++u) {
-                    const bool on = (e.z & row_bit[u]) != 0u;
-                    const unsigned off = on ? (u < kSlotsA ? e.x : e.y) + row_off[u] : kOob;
-                    v[u][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(u < kSlotsA ? ra : rb, off, 0, 0));
-                }
+            } else {
+                const __amdgpu_buffer_rsrc_t r = u < kSlotsA ? ra : rb;
+                v[u][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, t.x + row_off[u], 0, 0));
+                v[u][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, t.y + row_off[u], 0, 0));
+                v[u][2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, t.z + row_off[u], 0, 0));
+                v[u][3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, t.w + row_off[u], 0, 0));
             }
         }
     };
@@ -766,13 +764,28 @@ static int linear_impl(const float* x, const float* w, const float* bias, int ac
 
 // ---- weight gradients: the inner dimension (the minibatch's rows / the batch's output pixels) is cut into S slices, the slices'
 // partial results land in the caller's workspace and k_fold_slices sums them in slice order.
+// The slice count for `tiles` output tiles: the weight-gradient kernels hold two workgroups per CU (LDS), so the grid is dealt in
+// rounds of 2 x 256 workgroups and a round with two workgroups in it costs what a full one does (1026 workgroups measured 611 us
+// where 504 take 410): the S <= most that wastes the least of its last round, the smallest such S (fewer partial filters to fold).
+static int slices_for(long long tiles, long long most) {
+    constexpr long long kSlots = 2 * 256;
+    if (most < 1) most = 1;
+    if (most > 4096) most = 4096;
+    long long best = 1;
+    double best_util = 0.0;
+    for (long long S = 1; S <= most && tiles * S <= 4 * kSlots; ++S) {
+        const long long wgs = tiles * S, rounds = (wgs + kSlots - 1) / kSlots;
+        const double util = (double)wgs / (double)(rounds * kSlots);
+        if (util > best_util + 0.02) {
+            best_util = util;
+            best = S;
+        }
+    }
+    return (int)best;
+}
 static int linear_wgrad_slices(long long M, int N, int K) {
     const long long tiles = (long long)((N + 127) / 128) * ((K + 127) / 128);
-    long long s = (1024 + tiles - 1) / tiles;                 // about 1024 workgroups
-    const long long most = (M + 255) / 256;                   // at least 8 chunks of 32 rows per slice
-    if (s > most) s = most;
-    if (s < 1) s = 1;
-    return (int)s;
+    return slices_for(tiles, (M + 255) / 256);                // at least 8 chunks of 32 rows per slice
 }
 extern "C" size_t aurppo_linear_wgrad_ws_bytes(long long M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
@@ -820,10 +833,7 @@ bool conv_wgrad_plan(int B, int Ci, int Co, int H, int W, int pad, ConvWgradPlan
     p->n_tiles_m = (Co + 64 * p->WM - 1) / (64 * p->WM);
     p->n_tiles_n = (NK + 64 * (4 / p->WM) - 1) / (64 * (4 / p->WM));
     const long long tiles = (long long)p->n_tiles_m * p->n_tiles_n;
-    long long S = (1024 + tiles - 1) / tiles;
-    const long long most = (M + 511) / 512;                  // at least 16 chunks of 32 pixels per slice
-    if (S > most) S = most;
-    if (S < 1) S = 1;
+    long long S = slices_for(tiles, (M + 511) / 512);       // at least 16 chunks of 32 pixels per slice
     long long pps = ((M + S - 1) / S + 31) / 32 * 32;
     // 32-bit offsets relative to the slice's first image: the images a slice touches must span less than 2^31 bytes of either tensor
     const long long per_img = 4 * (HoWo * Co > HW * Ci ? HoWo * Co : HW * Ci);
