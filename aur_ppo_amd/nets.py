@@ -68,7 +68,8 @@ class _LinearSplitK(torch.autograd.Function):
 class _LinearTanhFn(torch.autograd.Function):
     """``tanh(x W^T + b)`` as ONE kernel forward (csrc/conv.hip::k_linear with bias + tanh in its epilogue) -- a hidden layer of
     src/nets/nets.py:21-27 for the shapes the fused K7 / K7w steps do not cover; backward: tanh' from the saved output, the input
-    gradient on the same kernel (mode 1), the weight gradient with the split over the batch of ``_LinearSplitK``."""
+    gradient on the same kernel (mode 1), the weight gradient on k_linear_wgrad where both of its dimensions fill a 128 x 128 tile,
+    else with the split over the batch of ``_LinearSplitK``."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -86,7 +87,9 @@ class _LinearTanhFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = H.linear_nobias(gz, weight.detach(), 1) if H.linear_ok(gz, weight.shape[0], weight.shape[1]) else gz @ weight
         m, s = x.shape[0], _LinearSplitK.SLABS
-        if m % s == 0 and m >= _LinearSplitK.MIN_ROWS:
+        if min(gz.shape[1], x.shape[1]) >= 128 and H.linear_wgrad_ok(gz, x):
+            gw = H.linear_wgrad(gz, x)       # k_linear_wgrad: 142 us at 256 x 256 x 131 072 where the split-batch bmm + sum takes 202
+        elif m % s == 0 and m >= _LinearSplitK.MIN_ROWS:
             gw = torch.bmm(gz.view(s, m // s, -1).transpose(1, 2), x.view(s, m // s, -1)).sum(0)
         else:
             gw = gz.t() @ x

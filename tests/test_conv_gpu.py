@@ -113,6 +113,7 @@ def test_encoder_with_k11_matches_the_stock_encoder(monkeypatch):
     from aur_ppo_amd import hip_ops as Hh
     from aur_ppo_amd.base_cnns import base_encoder
     monkeypatch.setattr(Hh, "CONV3X3_MIN_PIXELS", 1)       # (the size rule would hand this small batch to the library)
+    monkeypatch.setattr(Hh, "K12_MIN_PIXELS", 1)           # ... and its weight gradients (K12)
     torch.manual_seed(0)
     enc = base_encoder(obs_shape=(2, 128, 128), out_dim=128).cuda()
     obs = torch.rand(6, 1, 128, 128, device="cuda")

@@ -97,6 +97,7 @@ def test_robot_update_with_the_hand_written_convolutions_matches_cpu_restatement
     same comparison with K11 carrying every hidden convolution it supports -- step 1 at 1e-5, later steps at 2e-4."""
     from aur_ppo_amd import hip_ops as Hh
     monkeypatch.setattr(Hh, "CONV3X3_MIN_PIXELS", 1)
+    monkeypatch.setattr(Hh, "K12_MIN_PIXELS", 1)           # the weight gradients of the hidden blocks on K12
     calls = []
     real = Hh.conv3x3
     monkeypatch.setattr(Hh, "conv3x3", lambda x, w, p: (calls.append(tuple(x.shape)), real(x, w, p))[1])
