@@ -872,7 +872,7 @@ extern "C" int aurppo_conv3x3_wgrad_f32(const float* dy, const float* x, float* 
     hipStream_t st = (hipStream_t)stream;
     const dim3 g((unsigned)((long long)p.n_tiles_m * p.n_tiles_n * p.S)), blk(kConvThreads);
     // a quad of output pixels stays inside one row of its image, whose 16-byte pieces are aligned
-    const bool quad = a.Wo % 4 == 0 && W >= 4 && pad <= 1 && aligned_to(dy, 16) && getenv("AURPPO_K12_NOQUAD") == nullptr;
+    const bool quad = a.Wo % 4 == 0 && W >= 4 && pad <= 1 && aligned_to(dy, 16);
     if (p.WM == 2) {
         if (quad) hipLaunchKernelGGL((k_conv3x3_wgrad<2, true>), g, blk, 0, st, a);
         else hipLaunchKernelGGL((k_conv3x3_wgrad<2, false>), g, blk, 0, st, a);

@@ -534,23 +534,27 @@ def main_robot(args, json_fd):
     ms = res["ms_per_update"]
     flops = res["conv_flops_per_update"]
     roofline = {"bound": "mfma",
-                "kernel": "MIOpen convolutions of the actor / critic encoders, in aggregate (Winograd forward + data gradients, "
-                          "implicit-GEMM weight gradients, its layout transposes); K9 / K10 (csrc/pool.hip) are HBM-bound and listed in `top`",
+                "kernel": "the convolution kernels of the actor / critic encoders, in aggregate: K11 / K12 (csrc/conv.hip: forward, input and "
+                          "weight gradients of the hidden blocks as fp32-equivalent products on bf16 MFMAs) and what stays with MIOpen (the "
+                          "16 -> 32 block's gradients, the 3x3 -> 1x1 tail, its layout transposes) -- `hand_written_conv_ms` / `miopen_conv_ms`; "
+                          "K9 / K10 (csrc/pool.hip) are HBM-bound and listed in `top`",
                 "achieved": kt.get("library_conv_tflops"), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(kt["library_conv_tflops"] / MFMA_F32_PEAK_TFLOPS, 4) if kt.get("library_conv_tflops") else None,
                 "traffic": None,
                 "algorithmic_conv_flops_per_update": flops,
                 "whole_update_frac_of_fp32_mfma_peak": res["frac_of_fp32_mfma_peak"],
-                "library_conv_share_of_gpu_time": kt.get("library_conv_share"), "top": kt.get("top"),
+                "conv_share_of_gpu_time": kt.get("library_conv_share"), "hand_written_conv_ms": kt.get("hand_written_conv_ms"),
+                "miopen_conv_ms": kt.get("miopen_conv_ms"), "top": kt.get("top"),
                 "how": "direct-convolution FLOPs of both encoders, forward + both gradients (tools/bench_robot.py::conv_flops), over the "
-                       "summed device time of the library's convolution kernels in one more steady-state update under torch.profiler in "
-                       "this process; fp32 MFMA peak: the library runs fp32 kernels (Winograd does fewer multiplies than it is credited)"}
+                       "summed device time of every convolution kernel in one more steady-state update under torch.profiler in this "
+                       "process; priced at the fp32 MFMA peak the same FLOPs would need (K11 / K12 issue six bf16 products per fp32 product: "
+                       "their own pipe's ceiling is 2 500 / 6 = 417 TFLOP/s; Winograd does fewer multiplies than it is credited)"}
     out = {"metric": "env-steps/sec through GAE+PPO-update at num_envs=4096,T=128; 1/2/4/8 GPU",
            "value": N * T / (ms * 1e-3), "unit": "env-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": max(1, args.warmup),
            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": res["workload"] + f" -- BASELINE config {cfg}" + (" (per-GPU shard of 2048 envs / 8 GPUs)" if cfg == 5 else "")
                                   + ", plain-CNN robot_actor_critic, NOT the headline configuration",
-                      "policy": res["policy"], "minibatch_step": "K3 gather + K10 first block + MIOpen convolutions + K9 block tails + K5 loss + K6b"},
+                      "policy": res["policy"], "minibatch_step": "K3 gather + K10 first block + K11 / K12 hidden convolutions (MIOpen: the 16 -> 32 block's gradients, the 1x1 tail) + K9 block tails + K5 loss + K6b"},
            "roofline": roofline, "cpu_baseline": base, "parity_checked": bool(parity["ok"]) if parity else False,
            "parity": parity if parity else "not run (--cpu-baseline-updates 0 / --no-parity)", "graph_fallback": None}
     sys.stdout.flush()

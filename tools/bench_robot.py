@@ -116,11 +116,14 @@ def run(config=3, envs=0, steps=0, epochs=4, minibatches=4, updates=2, warmup=1,
         for e in rows[:30]:
             print(f"  {e.device_time_total / 1e3:9.1f} ms {100 * e.device_time_total / tot:5.1f}%  x{e.count:<6d} {e.key[:120]}", file=sys.stderr)
         ours = ("k_brp", "k_first_block", "k_gae", "k_gather", "k_loss", "k_adv", "k_clip", "k_sqnorm", "k_fy", "k_mt", "k_weighted", "k_pack")
-        lib = [e for e in rows if not e.key.startswith(ours) and any(m in e.key for m in CONV_MARKS)]
-        lib_us = sum(e.device_time_total for e in lib)
+        # every convolution kernel of the two encoders (K11 / K12 are named k_conv3x3*; the rest is the library's, its layout transposes included)
+        conv = [e for e in rows if not e.key.startswith(ours) and any(m in e.key for m in CONV_MARKS)]
+        lib_us = sum(e.device_time_total for e in conv)
+        hand_us = sum(e.device_time_total for e in conv if "k_conv3x3" in e.key or "k_fold_slices" in e.key)
         out["kernel_table"] = {"gpu_ms_per_update": round(tot / 1e3, 1),
                                "library_conv_ms": round(lib_us / 1e3, 1), "library_conv_share": round(lib_us / tot, 3),
                                "library_conv_tflops": round(flops / (lib_us * 1e-6) / 1e12, 1) if lib_us else None,
+                               "hand_written_conv_ms": round(hand_us / 1e3, 1), "miopen_conv_ms": round((lib_us - hand_us) / 1e3, 1),
                                "top": [{"kernel": e.key[:100], "ms": round(e.device_time_total / 1e3, 2), "share": round(e.device_time_total / tot, 4),
                                         "launches": e.count, "avg_us": round(e.device_time_total / max(e.count, 1), 1)} for e in rows[:12]],
                                "how": "torch.profiler (CUDA activity) over one more steady-state update in this process"}
