@@ -524,25 +524,41 @@ __global__ __launch_bounds__(kConvThreads, 2) void k_conv3x3_wgrad(const ConvWgr
             row_tap[u] = 1 + (n - 9 * ci);
         }
     }
+    // The table of chunk c: lane i < 32 of EVERY wave decomposes pixel i (two divisions by float reciprocal + fix-up: the slice's
+    // pixel indices stay below 2^23, conv_wgrad_plan) and wave w fills rows w, w + 4, w + 8 -- left to 32 lanes of one wave, the
+    // nine taps and two integer divisions were ~190 vector instructions per chunk on the wave every barrier waits for.
+    const float inv_howo = 1.0f / (float)HoWo, inv_wo = 1.0f / (float)a.Wo;
+    auto fdiv = [](int n, int d, float inv, int& rem) {
+        int q = (int)((float)n * inv);
+        int r = n - q * d;
+        if (r < 0) { q -= 1; r += d; }
+        else if (r >= d) { q += 1; r -= d; }
+        rem = r;
+        return q;
+    };
     auto table = [&](int c) {
-        if (tid < 32) {
-            const int i = c * 32 + tid;
+        if (lane < 32) {
+            const int i = c * 32 + lane;
             unsigned (*const tab)[32] = s_tab[c % 3];
-            if (i < n_px) {
-                const int mrel = r_lo + i;                       // relative to the first pixel of image b_lo
-                const int b = mrel / HoWo, r = mrel - b * HoWo;
-                const int y = r / a.Wo, x = r - y * a.Wo;
-                tab[0][tid] = (unsigned)(b * a.Co * HoWo + r) * 4u;
-                const int base = b * a.Ci * HW + (y - a.pad) * a.W + (x - a.pad);
+            int r, x;
+            const int b = fdiv(r_lo + i, HoWo, inv_howo, r);        // (relative to the first pixel of image b_lo)
+            const int y = fdiv(r, a.Wo, inv_wo, x);
+            const int base = b * a.Ci * HW + (y - a.pad) * a.W + (x - a.pad);
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const int iy = y + t / 3 - a.pad, ix = x + t % 3 - a.pad;
-                    const bool in = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-                    tab[1 + t][tid] = in ? (unsigned)(base + (t / 3) * a.W + t % 3) * 4u : kOob;
+            for (int k = 0; k < 3; ++k) {
+                const int t = w + 4 * k;                             // (wave-uniform)
+                if (t < 10) {
+                    unsigned e;
+                    if (t == 0) {
+                        e = (unsigned)(b * a.Co * HoWo + r) * 4u;
+                    } else {
+                        const int ky = (t - 1) / 3, kx = (t - 1) - 3 * ky;
+                        const int iy = y + ky - a.pad, ix = x + kx - a.pad;
+                        const bool in = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+                        e = in ? (unsigned)(base + ky * a.W + kx) * 4u : kOob;
+                    }
+                    tab[t][lane] = i < n_px ? e : kOob;
                 }
-            } else {
-#pragma unroll
-                for (int t = 0; t < 10; ++t) tab[t][tid] = kOob;
             }
         }
     };
@@ -838,8 +854,9 @@ bool conv_wgrad_plan(int B, int Ci, int Co, int H, int W, int pad, ConvWgradPlan
     // 32-bit offsets relative to the slice's first image: the images a slice touches must span less than 2^31 bytes of either tensor
     const long long per_img = 4 * (HoWo * Co > HW * Ci ? HoWo * Co : HW * Ci);
     if (per_img * 2 >= (1ll << 31)) return false;
-    while (pps > 32 && (pps / HoWo + 2) * per_img >= (1ll << 31)) pps = (pps / 2 + 31) / 32 * 32;
-    if ((pps / HoWo + 2) * per_img >= (1ll << 31)) return false;
+    // ... and its pixel indices, counted from the first pixel of its first image, must stay exact in fp32 (the kernel's divisions)
+    while (pps > 32 && ((pps / HoWo + 2) * per_img >= (1ll << 31) || pps + HoWo >= (1ll << 23))) pps = (pps / 2 + 31) / 32 * 32;
+    if ((pps / HoWo + 2) * per_img >= (1ll << 31) || pps + HoWo >= (1ll << 23)) return false;
     S = (M + pps - 1) / pps;
     if (S * tiles >= (1ll << 31) || S > (1 << 20)) return false;
     p->S = (int)S;
