@@ -679,7 +679,9 @@ constexpr int oIvar = oLs + 4 * AP;                    // float [AP]
 constexpr int oRec = oIvar + 4 * AP;                   // float4 [R]
 constexpr int oSrc = oRec + 16 * R;                    // int [R]
 constexpr int oIdx = oSrc + 4 * R;                     // int [2][R]
-constexpr int kBytes = oIdx + 4 * 2 * R;
+constexpr int oStage = (oIdx + 4 * 2 * R + 15) / 16 * 16;      // float [R][HPW]: the next tile's rows as they arrive (LDS-DMA)
+constexpr int oStageA = oStage + 4 * R * HPW;          // float [R][16]: its action rows
+constexpr int kBytes = oStageA + 4 * R * 16;
 static_assert(oH % 16 == 0 && oW3 % 16 == 0 && oDo % 16 == 0 && oOut % 16 == 0 && oRec % 16 == 0, "16-byte alignment of the images");
 static_assert(kBytes <= 160 * 1024, "one workgroup per CU");
 
@@ -718,6 +720,26 @@ __device__ __forceinline__ Frag3 f_rows16_p(const char* img, int f0, int lane) {
 #pragma unroll
     for (int p = 0; p < 3; ++p) f.p[p] = lds_b128(img + p * PL + o);
     return f;
+}
+// LDS-DMA: 16 / 4 bytes per lane from global memory straight into LDS at dst + lane * 16 / 4 (wave-uniform dst), no registers
+__device__ __forceinline__ void dma16(const void* src, void* dst_wave_uniform) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst_wave_uniform, 16, 0, 0);
+}
+__device__ __forceinline__ void dma4(const void* src, void* dst_wave_uniform) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst_wave_uniform, 4, 0, 0);
+}
+// sum / maximum over the 16 lanes of a DPP row (every lane gets the result)
+__device__ __forceinline__ float row16_sum(float v) {
+#pragma unroll
+    for (int m = 8; m > 0; m >>= 1) v += __shfl_xor(v, m, 16);
+    return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+#pragma unroll
+    for (int m = 8; m > 0; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 16));
+    return v;
 }
 // tanh(acc + bias) of a 32x32 block into an F image, four values (one 8-byte store per plane) at a time
 template <int PL>
@@ -806,9 +828,50 @@ __global__ __launch_bounds__(256) void k_mlpw3_prep(const float* __restrict__ pa
     }
 }
 
+// Diagnostic build only (-DK7W_STAMPS, tools/k7w_stamps.py): thread 0 of every workgroup accumulates, per segment of the tile loop,
+// the cycles up to its closing barrier (work) and inside it (wait)
+#ifdef K7W_STAMPS
+__device__ unsigned long long g_k7w_stamps[kMaxSlabs][32];
+#define WBAR(k)                                                        \
+    do {                                                               \
+        if (tid == 0) {                                                \
+            const unsigned long long t_ = __builtin_readcyclecounter(); \
+            wst[(k)] += t_ - wt0;                                      \
+            wt0 = t_;                                                  \
+        }                                                              \
+        __syncthreads();                                               \
+        if (tid == 0) {                                                \
+            const unsigned long long t_ = __builtin_readcyclecounter(); \
+            wst[10 + (k)] += t_ - wt0;                                 \
+            wt0 = t_;                                                  \
+        }                                                              \
+    } while (0)
+// (inside a segment: cycles since the last stamp go to slot k, and stay part of the segment's work)
+#define WSUB(k)                                                        \
+    do {                                                               \
+        if (tid == 0) {                                                \
+            const unsigned long long t_ = __builtin_readcyclecounter(); \
+            wst[(k)] += t_ - wsub0;                                    \
+            wsub0 = t_;                                                \
+        }                                                              \
+    } while (0)
+#define WSUB0() do { if (tid == 0) wsub0 = __builtin_readcyclecounter(); } while (0)
+#else
+#define WBAR(k) __syncthreads()
+#define WSUB(k) do { } while (0)
+#define WSUB0() do { } while (0)
+#endif
+
 template <int NL>
 __global__ __launch_bounds__(256, 1) void k_mlpw3_step(const WideArgs a) {
     using namespace w3;
+#ifdef K7W_STAMPS
+    unsigned long long wst[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) wst[k] = 0;
+    unsigned long long wt0 = 0, wsub0 = 0;
+    const unsigned long long wt_entry = __builtin_readcyclecounter();
+#endif
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
     __shared__ double s_red[2][kThreads / kWave];
     __shared__ float s_mean, s_std;
@@ -879,6 +942,11 @@ __global__ __launch_bounds__(256, 1) void k_mlpw3_step(const WideArgs a) {
     const float mean = s_mean, denom = s_std + 1e-8f;
     const float invM = 1.0f / (float)a.h.M;
     const float g_ent = -a.h.ent_coef * invM;
+    // loss lanes: lane k16 of a DPP row works on head output k16 of rows lrow and lrow + 16
+    const int k16 = tid & 15, lrow = tid >> 4;
+    const float my_ls = sLs[k16], my_ivar = sIvar[k16];
+    float ent_c = 0.0f;                                     // the Gaussian's entropy: the same for every row
+    for (int k = 0; k < A; ++k) ent_c += (0.5f + 0.9189385332046727f) + sLs[k];
 
     // persistent accumulators: dW_l blocks (out-block ob, in-block cb), the head's two 16x16 blocks, bias columns
     f32x16 gW[NL][4];
@@ -942,32 +1010,42 @@ __global__ __launch_bounds__(256, 1) void k_mlpw3_step(const WideArgs a) {
     const int n_tiles = (a.h.M + R - 1) / R;
     // staging: 32 chunk slots of 4 columns per row (128 state floats), four slots per thread
     const bool vec4 = (D % 4 == 0) && ((reinterpret_cast<size_t>(a.obs) & 15) == 0);
-    float xr[16], ar[2];
+    unsigned xok = 0u;                // which staged pieces are real (bit u: state piece u of this thread; bit 16 + u: action piece u)
     float4 p_rec = make_float4(0.f, 0.f, 0.f, 0.f);
-    int p_src = -1, n_idx = -1;
+    int p_src = -1;
     auto load_idx = [&](int tile) -> int {
         const int m = tile * R + tid;
         return (tile < n_tiles && m < a.h.M) ? a.idx[m] : -1;
     };
     const float* const act_base = a.actions ? a.actions : reinterpret_cast<const float*>(a.rec) + 4;
     const int act_stride = a.actions ? AW : 16;
+    char* const sStage = ldsb + oStage;
+    char* const sStageA = ldsb + oStageA;
+    // The next tile's rows go from HBM straight into an LDS staging area (LDS-DMA: lane l of a wave writes 16 / 4 bytes at the
+    // wave's base + l x 16 / 4, which IS the [row][column] order of the pieces a wave asks for), unconditionally (a piece that is
+    // not real reads element 0; `xok` remembers which are).  As loads into registers -- sixteen values per thread held for a whole
+    // tile in a kernel that has no register to spare -- their destinations doubled as temporaries, and the waits the compiler put
+    // in front of those reuses stood the wave through the gathers' HBM latency in the middle of layer 1 (tools/k7w_stamps.py: F1 took
+    // 7.5-8.1 k cycles for its 24 matrix instructions).
     auto prefetch = [&](const int* sidx) {
+        xok = 0u;
         if (vec4) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int e = tid + u * kThreads, r = e >> 5, c4 = (e & 31) * 4;
                 const int src = sidx[r];
                 const bool ok = src >= 0 && c4 < D;
-                const float4 v = *reinterpret_cast<const float4*>(a.obs + (ok ? (size_t)src * D + c4 : (size_t)0));
-                xr[4 * u + 0] = ok ? v.x : 0.0f; xr[4 * u + 1] = ok ? v.y : 0.0f;
-                xr[4 * u + 2] = ok ? v.z : 0.0f; xr[4 * u + 3] = ok ? v.w : 0.0f;
+                dma16(a.obs + (ok ? (size_t)src * D + c4 : (size_t)0), sStage + (w * 64 + u * kThreads) * 16);
+                xok |= ok ? (1u << u) : 0u;
             }
         } else {
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const int e = tid + u * kThreads, r = e >> 7, c = e & 127;
                 const int src = sidx[r];
-                xr[u] = (src >= 0 && c < D) ? a.obs[(size_t)src * D + c] : 0.0f;
+                const bool ok = src >= 0 && c < D;
+                dma4(a.obs + (ok ? (size_t)src * D + c : (size_t)0), sStage + (w * 64 + u * kThreads) * 4);
+                xok |= ok ? (1u << u) : 0u;
             }
         }
         if (net == 0) {
@@ -975,13 +1053,23 @@ __global__ __launch_bounds__(256, 1) void k_mlpw3_step(const WideArgs a) {
             for (int u = 0; u < 2; ++u) {
                 const int e = tid + u * kThreads, r = e >> 4, c = e & 15;
                 const int sa = sidx[r];
-                ar[u] = (sa >= 0 && c < AW) ? act_base[(size_t)sa * act_stride + c] : 0.0f;
+                const bool ok = sa >= 0 && c < AW;
+                dma4(act_base + (ok ? (size_t)sa * act_stride + c : (size_t)0), sStageA + (w * 64 + u * kThreads) * 4);
+                xok |= ok ? (1u << (16 + u)) : 0u;
             }
         }
-        if (tid < R) {
-            p_src = sidx[tid];
-            if (p_src >= 0) p_rec = a.rec[(size_t)p_src * a.rec_stride];
-        }
+        // (every thread, no branch: a conditional load is a write to its destination on the other path, and the wait the compiler
+        // puts in front of that write is a wait for every load above it)
+        p_src = sidx[tid & (R - 1)];
+        p_rec = a.rec[(size_t)(p_src >= 0 ? p_src : 0) * a.rec_stride];
+    };
+    // the index row of the tile three ahead, the same way: raw value + whether it is real
+    int n_raw = 0;
+    bool n_ok = false;
+    auto prefetch_idx = [&](int tile) {
+        const int m = tile * R + (tid & (R - 1));
+        n_ok = tile < n_tiles && m < a.h.M;
+        n_raw = a.idx[n_ok ? m : 0];
     };
     __shared__ int s_tile[4];
     unsigned* const ctr = a.tile_counter + net;
@@ -1003,11 +1091,18 @@ __global__ __launch_bounds__(256, 1) void k_mlpw3_step(const WideArgs a) {
     }
     __syncthreads();
     prefetch(sIdx);
-    if (tid < R) n_idx = load_idx(s_tile[2]);
+    prefetch_idx(s_tile[2]);
 
+#ifdef K7W_STAMPS
+    wt0 = __builtin_readcyclecounter();
+    wst[20] = wt0 - wt_entry;            // prologue
+#endif
     for (int it = 0;; ++it) {
         const int tile = s_tile[it & 3];
         if (tile >= n_tiles) break;
+#ifdef K7W_STAMPS
+        wst[21] += 1;                    // tiles
+#endif
         const int tile3 = s_tile[(it + 3) & 3];
         int ln = lane;
         asm volatile("" : "+v"(ln));          // opaque per-tile copy: LDS addresses are re-derived inside the phases, not hoisted and spilled
@@ -1018,40 +1113,44 @@ __global__ __launch_bounds__(256, 1) void k_mlpw3_step(const WideArgs a) {
             lane16 = ln * 16;
         }
         // ---- land the prefetched tile as bf16 planes
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's own pieces have landed in the staging area
         if (vec4) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int e = tid + u * kThreads, r = e >> 5, c4 = (e & 31) * 4;
-                if (c4 < D) store_x4(sX + (c4 >> 6) * kXHalf, r, c4 & 63, xr[4 * u + 0], xr[4 * u + 1], xr[4 * u + 2], xr[4 * u + 3]);
+                const bool ok = (xok >> u) & 1u;
+                const float4 v = *reinterpret_cast<const float4*>(sStage + e * 16);
+                if (c4 < D) store_x4(sX + (c4 >> 6) * kXHalf, r, c4 & 63, ok ? v.x : 0.0f, ok ? v.y : 0.0f, ok ? v.z : 0.0f, ok ? v.w : 0.0f);
             }
         } else {
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const int e = tid + u * kThreads, r = e >> 7, c = e & 127;
-                if (c < D) store_x1(sX + (c >> 6) * kXHalf, r, c & 63, xr[u]);
+                const float v = *reinterpret_cast<const float*>(sStage + e * 4);
+                if (c < D) store_x1(sX + (c >> 6) * kXHalf, r, c & 63, ((xok >> u) & 1u) ? v : 0.0f);
             }
         }
         if (net == 0) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int e = tid + u * kThreads;
-                sAct[(e >> 4) * LDO + (e & 15)] = ar[u];
+                const float v = *reinterpret_cast<const float*>(sStageA + e * 4);
+                sAct[(e >> 4) * LDO + (e & 15)] = ((xok >> (16 + u)) & 1u) ? v : 0.0f;
             }
         }
         if (tid < R) {
             sSrc[tid] = p_src;
             sRec[tid] = p_rec;
-            sIdx[(it & 1) * R + tid] = n_idx;
+            sIdx[(it & 1) * R + tid] = n_ok ? n_raw : -1;
         }
-        __syncthreads();
-        prefetch(sIdx + ((it + 1) & 1) * R);      // the next tile's rows, behind this tile's math
-        if (tid < R) n_idx = load_idx(tile3);
+        WBAR(0);
 
         // ---- forward: H_1 .. H_NL
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
+            f32x16 acc = zero16();
+            WSUB0();
             if (cb < HB) {
-                f32x16 acc = zero16();
                 if (l == 0) {
                     load_w_hi(0, 0, nksD);
 #pragma unroll
@@ -1067,13 +1166,28 @@ __global__ __launch_bounds__(256, 1) void k_mlpw3_step(const WideArgs a) {
                         if (ks & 1) __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#ifdef K7W_STAMPS
+            { float sink = acc[0] + acc[15]; asm volatile("" :: "v"(sink)); }      // the chain has drained
+#endif
+            WSUB(l == 0 ? 24 : 28);
+            if (l == 0) {
+                // the next tile's rows, behind this tile's math.  Requested HERE, behind layer 1's products: the wait for their weight
+                // slice (requested in the previous trip of the loop) is a vmcnt(0), and ahead of it these gathers' whole HBM latency
+                // sat in every tile (tools/k7w_stamps.py: F1 took 8.1 k cycles for its 24 matrix instructions)
+                prefetch(sIdx + ((it + 1) & 1) * R);
+                prefetch_idx(tile3);
+            }
+            WSUB(25);
+            if (cb < HB) {
                 // the slice used next: the following layer's forward copy, or (behind the last layer) the top layer's backward copy
                 if (l + 1 < NL) load_w(l + 1, 0, nksH);
                 else if (NL > 1) load_w(NL - 1, 1, nksH);
                 tanh_store_p<kFPlaneW>(sH(l), cb * 32, acc, sB[l * HPW + cb * 32 + (ln & 31)], ln);
             }
-            __syncthreads();
+            WSUB(l == 0 ? 26 : 29);
+            WBAR(1 + l);
         }
         if (cb < 2) {   // head: 16 rows per wave on 16x16x32
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -1087,65 +1201,62 @@ __global__ __launch_bounds__(256, 1) void k_mlpw3_step(const WideArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) sOut[(cb * 16 + 4 * (ln >> 4) + e) * LDO + col] = acc[e] + bias;
         }
-        __syncthreads();
+        WBAR(4);
         int tile4 = 0;
         if (tid == 0) tile4 = stat ? tile + 4 * n_wg : (int)atomicAdd(ctr, 1u);
 
-        // ---- loss lanes (one per row): this net's half of the PPO terms; head outputs become their gradients, fp32 (column
-        // sums) and as a bf16-plane image (the two products below)
-        if (tid < R) {
-            float* out = sOut + tid * LDO;
-            if (sSrc[tid] >= 0) {
-                const float4 rc = sRec[tid];
-                if (net == 1) {
-                    const PpoSample t = ppo_sample(rc.x, rc.x, rc.y, out[0], rc.w, rc.z, mean, denom, invM, a.h);
+        // ---- loss lanes: this net's half of the PPO terms; head outputs become their gradients, fp32 (column sums) and as a
+        // bf16-plane image (the two products below).  SIXTEEN lanes per row (lane k = head output k; rows tid >> 4 and + 16), the
+        // sums over the outputs by butterfly inside the 16 lanes: as one lane per row walking its outputs, this phase was 6.2 k
+        // cycles of a 51.6 k-cycle tile with 224 of the workgroup's threads waiting (tools/k7w_stamps.py)
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int row = lrow + 16 * pass;
+            float* const out = sOut + row * LDO;
+            const bool live = sSrc[row] >= 0;
+            const float4 rc = sRec[row];
+            const float o_k = out[k16];
+            float g_out = 0.0f;                       // d loss / d head output k of this row
+            if (net == 1) {
+                if (k16 == 0 && live) {
+                    const PpoSample t = ppo_sample(rc.x, rc.x, rc.y, o_k, rc.w, rc.z, mean, denom, invM, a.h);
                     l_a += t.vl;
-                    out[0] = t.g_v;
+                    g_out = t.g_v;
                     g_b3c += t.g_v;
-                } else if (a.continuous) {
-                    const float* act = sAct + tid * LDO;
-                    float logp = 0.0f, ent = 0.0f;
-                    for (int k = 0; k < A; ++k) {
-                        const float ls = sLs[k];
-                        const float zk = act[k] - out[k];
-                        logp += (-(zk * zk) * (0.5f * sIvar[k]) - ls) - 0.9189385332046727f;
-                        ent += (0.5f + 0.9189385332046727f) + ls;
-                    }
-                    const PpoSample t = ppo_sample(logp, rc.x, rc.y, rc.w, rc.w, rc.z, mean, denom, invM, a.h);
-                    l_a += t.pg; l_b += ent; l_c += t.okl; l_d += t.kl; l_e += t.cf;
-                    for (int k = 0; k < A; ++k) {
-                        const float zk = act[k] - out[k];
-                        out[k] = t.g_logp * (zk * sIvar[k]);
-                        sDls[tid * LDO + k] = t.g_logp * (zk * zk * sIvar[k] - 1.0f) + g_ent;
+                }
+            } else if (a.continuous) {
+                const float zk = sAct[row * LDO + k16] - o_k;
+                const float logp = row16_sum(k16 < A ? (-(zk * zk) * (0.5f * my_ivar) - my_ls) - 0.9189385332046727f : 0.0f);
+                const PpoSample t = ppo_sample(logp, rc.x, rc.y, rc.w, rc.w, rc.z, mean, denom, invM, a.h);
+                if (live) {
+                    if (k16 == 0) { l_a += t.pg; l_b += ent_c; l_c += t.okl; l_d += t.kl; l_e += t.cf; }
+                    if (k16 < A) {
+                        g_out = t.g_logp * (zk * my_ivar);
+                        sDls[row * LDO + k16] = t.g_logp * (zk * zk * my_ivar - 1.0f) + g_ent;
                     }
                 } else {
-                    const float* act = sAct + tid * LDO;
-                    float mx = out[0];
-                    for (int k = 1; k < A; ++k) mx = fmaxf(mx, out[k]);
-                    float se = 0.0f;
-                    for (int k = 0; k < A; ++k) se += expf(out[k] - mx);
-                    const float lse = mx + logf(se);
-                    const int ai = (int)act[0];
-                    float logp = 0.0f, ent = 0.0f;
-                    for (int k = 0; k < A; ++k) {
-                        const float lpk = out[k] - lse;
-                        ent -= expf(lpk) * lpk;
-                        if (k == ai) logp = lpk;
-                    }
-                    const PpoSample t = ppo_sample(logp, rc.x, rc.y, rc.w, rc.w, rc.z, mean, denom, invM, a.h);
-                    l_a += t.pg; l_b += ent; l_c += t.okl; l_d += t.kl; l_e += t.cf;
-                    for (int k = 0; k < A; ++k) {
-                        const float lpk = out[k] - lse;
-                        const float pk = expf(lpk);
-                        out[k] = t.g_logp * ((k == ai ? 1.0f : 0.0f) - pk) + g_ent * (-pk * (lpk + ent));
-                    }
+                    sDls[row * LDO + k16] = 0.0f;
                 }
             } else {
-                for (int k = 0; k < AP; ++k) out[k] = sDls[tid * LDO + k] = 0.0f;
+                const bool in = k16 < A;
+                const float mx = row16_max(in ? o_k : -3.0e38f);
+                const float se = row16_sum(in ? expf(o_k - mx) : 0.0f);
+                const float lse = mx + logf(se);
+                const int ai = (int)sAct[row * LDO];
+                const float lpk = o_k - lse, pk = in ? expf(lpk) : 0.0f;
+                const float ent = -row16_sum(in ? pk * lpk : 0.0f);
+                const float logp = row16_sum(in && k16 == ai ? lpk : 0.0f);
+                const PpoSample t = ppo_sample(logp, rc.x, rc.y, rc.w, rc.w, rc.z, mean, denom, invM, a.h);
+                if (live) {
+                    if (k16 == 0) { l_a += t.pg; l_b += ent; l_c += t.okl; l_d += t.kl; l_e += t.cf; }
+                    if (in) g_out = t.g_logp * ((k16 == ai ? 1.0f : 0.0f) - pk) + g_ent * (-pk * (lpk + ent));
+                }
+                sDls[row * LDO + k16] = 0.0f;
             }
-            for (int k = 0; k < AP; ++k) store_plain1(sDo, kDoRowW, kDoPlaneW, k, tid, k < out_dim ? out[k] : 0.0f);
+            out[k16] = g_out;
+            store_plain1(sDo, kDoRowW, kDoPlaneW, k16, row, g_out);
         }
-        __syncthreads();
+        WBAR(5);
 
         // ---- head backward: column sums (d b3, d logstd), dH_NL -> dZ_NL (in place), dW3
         if (net == 0 && w == 3 && lane < 2 * AP) {
@@ -1168,7 +1279,7 @@ __global__ __launch_bounds__(256, 1) void k_mlpw3_step(const WideArgs a) {
             colsum += __shfl_xor(colsum, 32, kWave);
             gb[NL - 1] += colsum;
         }
-        __syncthreads();
+        WBAR(6);
         // ---- hidden layers, top down: dW_l, dH_{l-1} -> dZ_{l-1} (in place)
 #pragma unroll
         for (int l = NL - 1; l >= 1; --l) {
@@ -1197,7 +1308,7 @@ __global__ __launch_bounds__(256, 1) void k_mlpw3_step(const WideArgs a) {
                 colsum += __shfl_xor(colsum, 32, kWave);
                 gb[l - 1] += colsum;
             }
-            __syncthreads();
+            WBAR(6 + l);
         }
         // ---- dW_1: this wave's 32 state columns against every out-block
         if (cb < DB) {
@@ -1213,9 +1324,16 @@ __global__ __launch_bounds__(256, 1) void k_mlpw3_step(const WideArgs a) {
             }
         }
         if (tid == 0) s_tile[it & 3] = tile4;
-        __syncthreads();
+        WBAR(9);
     }
 
+#ifdef K7W_STAMPS
+    if (tid == 0) {
+        wst[22] = __builtin_readcyclecounter() - wt_entry;     // entry to the end of the tile loop
+#pragma unroll
+        for (int k = 0; k < 32; ++k) g_k7w_stamps[blockIdx.x][k] = wst[k];
+    }
+#endif
     // ---- this workgroup's half of the pair's slab
     float* slab = a.slabs + (size_t)pair * a.L.n_params;
     {
@@ -1248,25 +1366,26 @@ __global__ __launch_bounds__(256, 1) void k_mlpw3_step(const WideArgs a) {
         if (lane < A) slab[a.L.b[0][NL] + lane] = g_head;
         if (a.continuous && lane >= AP && lane - AP < A) slab[a.L.logstd + lane - AP] = g_head;
     }
-    if (cb == 0) {
-        float c = lane < R ? g_b3c : 0.0f;
-        double v5[5] = {l_a, l_b, l_c, l_d, l_e};
+    {   // the loss sums and the critic's bias gradient sit on lane 0 of every DPP row of all four waves
+        __shared__ double s_fin[kThreads / kWave][6];
+        double v6[6] = {l_a, l_b, l_c, l_d, l_e, (double)g_b3c};
 #pragma unroll
-        for (int off = 16; off > 0; off >>= 1) c += __shfl_down(c, off, kWave);
+        for (int q = 0; q < 6; ++q) {
+            double x = k16 == 0 ? v6[q] : 0.0;
 #pragma unroll
-        for (int q = 0; q < 5; ++q) {
-            double x = lane < R ? v5[q] : 0.0;
-#pragma unroll
-            for (int off = 16; off > 0; off >>= 1) x += __shfl_down(x, off, kWave);
-            v5[q] = x;
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, kWave);
+            if (lane == 0) s_fin[w][q] = x;
         }
-        if (lane == 0) {
+        __syncthreads();
+        if (tid == 0) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) v6[q] = ((s_fin[0][q] + s_fin[1][q]) + s_fin[2][q]) + s_fin[3][q];
             double* lp = a.loss_part + (size_t)pair * 8;
             if (net == 0) {
-                lp[0] = v5[0]; lp[2] = v5[1]; lp[3] = v5[2]; lp[4] = v5[3]; lp[5] = v5[4];
+                lp[0] = v6[0]; lp[2] = v6[1]; lp[3] = v6[2]; lp[4] = v6[3]; lp[5] = v6[4];
             } else {
-                slab[a.L.b[1][NL]] = c;
-                lp[1] = v5[0];
+                slab[a.L.b[1][NL]] = (float)v6[5];
+                lp[1] = v6[0];
                 lp[6] = (double)mean;
                 lp[7] = (double)s_std;
             }
@@ -1589,3 +1708,9 @@ extern "C" int aurppo_mlp_wide_act_f32(const float* obs, const float* noise, int
     AURPPO_LAUNCH_CHECK("k_mlpw_act");
     return AURPPO_OK;
 }
+
+#ifdef K7W_STAMPS
+extern "C" int aurppo_k7w_stamps_read(unsigned long long* host_out) {      // (kMaxSlabs, 32); diagnostic build only
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_k7w_stamps), sizeof(unsigned long long) * kMaxSlabs * 32) == hipSuccess ? 0 : -1;
+}
+#endif
