@@ -862,7 +862,11 @@ __device__ unsigned long long g_k7w_stamps[kMaxSlabs][32];
 #define WSUB0() do { } while (0)
 #endif
 
-template <int NL>
+// FULL: the hidden layers are 128 wide (four column blocks, eight k-steps) and DK > 0: layer 1 runs DK k-steps (state width <= 16 DK,
+// zero-padded) -- every trip count of the matrix chains is then a compile-time constant.  With run-time counts each k-step sat in
+// its own branch, and the wait the compiler places at such a join is lgkmcnt(0): the fragments requested for the NEXT k-step were
+// waited for before the current one's products were issued (75-87 cycles per matrix instruction, tools/k7w_stamps.py).
+template <int NL, bool FULL, int DK>
 __global__ __launch_bounds__(256, 1) void k_mlpw3_step(const WideArgs a) {
     using namespace w3;
 #ifdef K7W_STAMPS
@@ -880,7 +884,7 @@ __global__ __launch_bounds__(256, 1) void k_mlpw3_step(const WideArgs a) {
     const int net = (int)(blockIdx.x & 1), cb = w, pair = (int)(blockIdx.x >> 1);
     const int D = a.D, A = a.A, Hd = a.Hd;
     const int HB = (Hd + 31) >> 5, DB = (D + 31) >> 5;
-    const int nksD = (D + 15) >> 4, nksH = (Hd + 15) >> 4, nks2H = (Hd + 31) >> 5;
+    const int nksD = DK > 0 ? DK : (D + 15) >> 4, nksH = FULL ? 8 : (Hd + 15) >> 4, nks2H = FULL ? 4 : (Hd + 31) >> 5;
     const int AW = a.continuous ? A : 1;
     const int out_dim = net == 0 ? A : 1;
 
@@ -979,7 +983,9 @@ __global__ __launch_bounds__(256, 1) void k_mlpw3_step(const WideArgs a) {
 #ifdef K7W_EXP_NO_WLOAD       // timing experiment (WRONG results): the weight slices are fetched once per launch
         if (wbase != wbase0 + 0 || n_loaded++) return;
 #endif
-        const char* m = wbase + 2 * (size_t)(wop_slot(net, l, dir) * kWopSlot);
+        int wz = 0;
+        asm volatile("" : "+s"(wz));          // (an opaque zero per request: the loads stay where they are asked for)
+        const char* m = wbase + wz + 2 * (size_t)(wop_slot(net, l, dir) * kWopSlot);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
             if (ks < nks) {
@@ -991,7 +997,9 @@ __global__ __launch_bounds__(256, 1) void k_mlpw3_step(const WideArgs a) {
 #ifdef K7W_EXP_NO_WLOAD
         if (n_loaded_hi++) return;
 #endif
-        const char* m = wbase + 2 * (size_t)(wop_slot(net, l, dir) * kWopSlot);
+        int wz = 0;
+        asm volatile("" : "+s"(wz));
+        const char* m = wbase + wz + 2 * (size_t)(wop_slot(net, l, dir) * kWopSlot);
 #pragma unroll
         for (int ks = 4; ks < kWopKs; ++ks)
             if (ks < nks) {
@@ -1028,33 +1036,43 @@ __global__ __launch_bounds__(256, 1) void k_mlpw3_step(const WideArgs a) {
     // in front of those reuses stood the wave through the gathers' HBM latency in the middle of layer 1 (tools/k7w_stamps.py: F1 took
     // 7.5-8.1 k cycles for its 24 matrix instructions).
     auto prefetch = [&](const int* sidx) {
+        // (the rows' indices are read from LDS first, all of them, and a piece that is not real is pointed at element 0 by 32-bit
+        // selects: written as `ok ? row * D + c : 0` the 64-bit product sat in a branch per piece, each behind its own LDS wait --
+        // 1.8 k cycles to issue eight requests, tools/k7w_stamps.py)
         xok = 0u;
         if (vec4) {
+            int src[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) src[u] = sidx[(tid + u * kThreads) >> 5];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int e = tid + u * kThreads, r = e >> 5, c4 = (e & 31) * 4;
-                const int src = sidx[r];
-                const bool ok = src >= 0 && c4 < D;
-                dma16(a.obs + (ok ? (size_t)src * D + c4 : (size_t)0), sStage + (w * 64 + u * kThreads) * 16);
+                const int c4 = (tid & 31) * 4;
+                const bool ok = src[u] >= 0 && c4 < D;
+                const unsigned row = ok ? (unsigned)src[u] : 0u, col = ok ? (unsigned)c4 : 0u;
+                dma16(a.obs + ((size_t)row * (unsigned)D + col), sStage + (w * 64 + u * kThreads) * 16);
                 xok |= ok ? (1u << u) : 0u;
             }
         } else {
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const int e = tid + u * kThreads, r = e >> 7, c = e & 127;
-                const int src = sidx[r];
-                const bool ok = src >= 0 && c < D;
-                dma4(a.obs + (ok ? (size_t)src * D + c : (size_t)0), sStage + (w * 64 + u * kThreads) * 4);
+                const int s1 = sidx[r];
+                const bool ok = s1 >= 0 && c < D;
+                const unsigned row = ok ? (unsigned)s1 : 0u, col = ok ? (unsigned)c : 0u;
+                dma4(a.obs + ((size_t)row * (unsigned)D + col), sStage + (w * 64 + u * kThreads) * 4);
                 xok |= ok ? (1u << u) : 0u;
             }
         }
         if (net == 0) {
+            int sa[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) sa[u] = sidx[(tid + u * kThreads) >> 4];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int e = tid + u * kThreads, r = e >> 4, c = e & 15;
-                const int sa = sidx[r];
-                const bool ok = sa >= 0 && c < AW;
-                dma4(act_base + (ok ? (size_t)sa * act_stride + c : (size_t)0), sStageA + (w * 64 + u * kThreads) * 4);
+                const int c = tid & 15;
+                const bool ok = sa[u] >= 0 && c < AW;
+                const unsigned row = ok ? (unsigned)sa[u] : 0u, col = ok ? (unsigned)c : 0u;
+                dma4(act_base + ((size_t)row * (unsigned)act_stride + col), sStageA + (w * 64 + u * kThreads) * 4);
                 xok |= ok ? (1u << (16 + u)) : 0u;
             }
         }
@@ -1083,7 +1101,7 @@ __global__ __launch_bounds__(256, 1) void k_mlpw3_step(const WideArgs a) {
             s_tile[0] = t0; s_tile[1] = t0 + 1; s_tile[2] = t0 + 2; s_tile[3] = t0 + 3;
         }
     }
-    if (cb < HB) load_w(0, 0, nksD);                        // layer 1's slice for the first tile
+    if (FULL || cb < HB) load_w(0, 0, nksD);                        // layer 1's slice for the first tile
     __syncthreads();
     if (tid < R) {
         sIdx[tid] = load_idx(s_tile[0]);
@@ -1150,20 +1168,40 @@ __global__ __launch_bounds__(256, 1) void k_mlpw3_step(const WideArgs a) {
         for (int l = 0; l < NL; ++l) {
             f32x16 acc = zero16();
             WSUB0();
-            if (cb < HB) {
+            if (FULL || cb < HB) {
+                // (every chain below asks for the fragments of k-step ks + 1 BEFORE it issues the six products of k-step ks: with the
+                // reads and the products of a pair of k-steps in one scheduling region the compiler put the reads first and the wave
+                // waited out their latency in front of every pair -- 75-87 cycles per matrix instruction instead of 32,
+                // tools/k7w_stamps.py)
+                int lc = ln;
+                asm volatile("" : "+v"(lc));       // (an opaque copy per chain: its fragment addresses are formed here, not at the top of the tile)
                 if (l == 0) {
                     load_w_hi(0, 0, nksD);
+                    Frag3 f0 = x_rows(sX, 0, lc), f1 = f0;          // two fragment sets take turns (no copies between them)
 #pragma unroll
-                    for (int ks = 0; ks < kWopKs; ++ks) {
-                        if (ks < nksD) acc = mma32x3(x_rows(sX + (ks >> 2) * kXHalf, ks & 3, ln), wfrag(ks), acc);
-                        if (ks & 1) __builtin_amdgcn_sched_barrier(0);      // operand reads at most two k-steps ahead (registers)
+                    for (int ks = 0; ks < kWopKs; ks += 2) {
+                        if (DK > 0 ? ks + 1 < DK : ks + 1 < nksD) f1 = x_rows(sX + ((ks + 1) >> 2) * kXHalf, (ks + 1) & 3, lc);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (DK > 0 ? ks < DK : ks < nksD) acc = mma32x3(f0, wfrag(ks), acc);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (DK > 0 ? ks + 2 < DK : ks + 2 < nksD) f0 = x_rows(sX + ((ks + 2) >> 2) * kXHalf, (ks + 2) & 3, lc);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (DK > 0 ? ks + 1 < DK : ks + 1 < nksD) acc = mma32x3(f1, wfrag(ks + 1), acc);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 } else {
                     load_w_hi(l, 0, nksH);
+                    Frag3 f0 = f_cols_p<kFPlaneW>(sH(l - 1), 0, lc), f1 = f0;
 #pragma unroll
-                    for (int ks = 0; ks < kWopKs; ++ks) {
-                        if (ks < nksH) acc = mma32x3(f_cols_p<kFPlaneW>(sH(l - 1), ks, ln), wfrag(ks), acc);
-                        if (ks & 1) __builtin_amdgcn_sched_barrier(0);
+                    for (int ks = 0; ks < kWopKs; ks += 2) {
+                        if (FULL ? ks + 1 < 8 : ks + 1 < nksH) f1 = f_cols_p<kFPlaneW>(sH(l - 1), ks + 1, lc);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (FULL ? ks < 8 : ks < nksH) acc = mma32x3(f0, wfrag(ks), acc);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (FULL ? ks + 2 < 8 : ks + 2 < nksH) f0 = f_cols_p<kFPlaneW>(sH(l - 1), ks + 2, lc);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (FULL ? ks + 1 < 8 : ks + 1 < nksH) acc = mma32x3(f1, wfrag(ks + 1), acc);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             }
@@ -1180,7 +1218,7 @@ __global__ __launch_bounds__(256, 1) void k_mlpw3_step(const WideArgs a) {
                 prefetch_idx(tile3);
             }
             WSUB(25);
-            if (cb < HB) {
+            if (FULL || cb < HB) {
                 // the slice used next: the following layer's forward copy, or (behind the last layer) the top layer's backward copy
                 if (l + 1 < NL) load_w(l + 1, 0, nksH);
                 else if (NL > 1) load_w(NL - 1, 1, nksH);
@@ -1209,8 +1247,8 @@ __global__ __launch_bounds__(256, 1) void k_mlpw3_step(const WideArgs a) {
         // bf16-plane image (the two products below).  SIXTEEN lanes per row (lane k = head output k; rows tid >> 4 and + 16), the
         // sums over the outputs by butterfly inside the 16 lanes: as one lane per row walking its outputs, this phase was 6.2 k
         // cycles of a 51.6 k-cycle tile with 224 of the workgroup's threads waiting (tools/k7w_stamps.py)
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {      // (not unrolled: two passes' temporaries at once cost the 3-layer build 130 spilled registers)
             const int row = lrow + 16 * pass;
             float* const out = sOut + row * LDO;
             const bool live = sSrc[row] >= 0;
@@ -1266,7 +1304,7 @@ __global__ __launch_bounds__(256, 1) void k_mlpw3_step(const WideArgs a) {
             for (int r = 0; r < R; ++r) cs += src[r * LDO];
             g_head += cs;
         }
-        if (cb < HB) {
+        if (FULL || cb < HB) {
             char* const HL = sH(NL - 1);
             f32x16 acc = zero16();
             acc = mma32x3(plain_cols(sDo, kDoRowW, kDoPlaneW, 0, 0, ln), plain_cols(sW3, kW3RowW, kW3PlaneW, 0, cb * 32, ln), acc);
@@ -1283,24 +1321,42 @@ __global__ __launch_bounds__(256, 1) void k_mlpw3_step(const WideArgs a) {
         // ---- hidden layers, top down: dW_l, dH_{l-1} -> dZ_{l-1} (in place)
 #pragma unroll
         for (int l = NL - 1; l >= 1; --l) {
-            if (cb < HB) {
+            if (FULL || cb < HB) {
                 const char* const dZ = sH(l);
                 char* const Hp = sH(l - 1);
                 load_w_hi(l, 1, nksH);                      // (behind the dW chains below)
+                int lc = ln;
+                asm volatile("" : "+v"(lc));
+                {   // dW_l: eight (k-step, out-block) products, the next one's dZ fragment (and the next k-step's H fragment) asked for first
+                    Frag3 hb0 = f_rows_p<kFPlaneW>(Hp, cb * 32, 0, lc), hb1 = hb0;
+                    Frag3 d0 = f_rows_p<kFPlaneW>(dZ, 0, 0, lc), d1 = d0;
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const Frag3 hb = f_rows_p<kFPlaneW>(Hp, cb * 32, ks, ln);
-#pragma unroll
-                    for (int ob = 0; ob < 4; ++ob) {
-                        if (ob < HB) gW[l][ob] = mma32x3(f_rows_p<kFPlaneW>(dZ, ob * 32, ks, ln), hb, gW[l][ob]);
-                        if (ob & 1) __builtin_amdgcn_sched_barrier(0);
+                    for (int q = 0; q < 8; q += 2) {            // q = 4 ks + ob
+                        if (FULL || ((q + 1) & 3) < HB) d1 = f_rows_p<kFPlaneW>(dZ, ((q + 1) & 3) * 32, (q + 1) >> 2, lc);
+                        if (q == 2) hb1 = f_rows_p<kFPlaneW>(Hp, cb * 32, 1, lc);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (FULL || (q & 3) < HB) gW[l][q & 3] = mma32x3(d0, q < 4 ? hb0 : hb1, gW[l][q & 3]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (q + 2 < 8 && (FULL || ((q + 2) & 3) < HB)) d0 = f_rows_p<kFPlaneW>(dZ, ((q + 2) & 3) * 32, (q + 2) >> 2, lc);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (FULL || ((q + 1) & 3) < HB) gW[l][(q + 1) & 3] = mma32x3(d1, q < 4 ? hb0 : hb1, gW[l][(q + 1) & 3]);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
                 f32x16 acc = zero16();
+                {
+                    Frag3 f0 = f_cols_p<kFPlaneW>(dZ, 0, lc), f1 = f0;
 #pragma unroll
-                for (int ks = 0; ks < kWopKs; ++ks) {
-                    if (ks < nksH) acc = mma32x3(f_cols_p<kFPlaneW>(dZ, ks, ln), wfrag(ks), acc);
-                    if (ks & 1) __builtin_amdgcn_sched_barrier(0);
+                    for (int ks = 0; ks < kWopKs; ks += 2) {
+                        if (FULL ? ks + 1 < 8 : ks + 1 < nksH) f1 = f_cols_p<kFPlaneW>(dZ, ks + 1, lc);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (FULL ? ks < 8 : ks < nksH) acc = mma32x3(f0, wfrag(ks), acc);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (FULL ? ks + 2 < 8 : ks + 2 < nksH) f0 = f_cols_p<kFPlaneW>(dZ, ks + 2, lc);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (FULL ? ks + 1 < 8 : ks + 1 < nksH) acc = mma32x3(f1, wfrag(ks + 1), acc);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
                 if (l - 1 >= 1) load_w(l - 1, 1, nksH);
                 else load_w(0, 0, nksD);                    // layer 1's forward slice for the next tile
@@ -1313,14 +1369,21 @@ __global__ __launch_bounds__(256, 1) void k_mlpw3_step(const WideArgs a) {
         // ---- dW_1: this wave's 32 state columns against every out-block
         if (cb < DB) {
             const char* const dZ = sH(0);
+            int lc = ln;
+            asm volatile("" : "+v"(lc));
+            Frag3 xb0 = x_cols(sX + (cb >> 1) * kXHalf, 0, (cb & 1) * 32, lc), xb1 = xb0;
+            Frag3 d0 = f_rows_p<kFPlaneW>(dZ, 0, 0, lc), d1 = d0;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const Frag3 xb = x_cols(sX + (cb >> 1) * kXHalf, ks, (cb & 1) * 32, ln);
-#pragma unroll
-                for (int ob = 0; ob < 4; ++ob) {
-                    if (ob < HB) gW[0][ob] = mma32x3(f_rows_p<kFPlaneW>(dZ, ob * 32, ks, ln), xb, gW[0][ob]);
-                    if (ob & 1) __builtin_amdgcn_sched_barrier(0);
-                }
+            for (int q = 0; q < 8; q += 2) {
+                if (FULL || ((q + 1) & 3) < HB) d1 = f_rows_p<kFPlaneW>(dZ, ((q + 1) & 3) * 32, (q + 1) >> 2, lc);
+                if (q == 2) xb1 = x_cols(sX + (cb >> 1) * kXHalf, 1, (cb & 1) * 32, lc);
+                __builtin_amdgcn_sched_barrier(0);
+                if (FULL || (q & 3) < HB) gW[0][q & 3] = mma32x3(d0, q < 4 ? xb0 : xb1, gW[0][q & 3]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (q + 2 < 8 && (FULL || ((q + 2) & 3) < HB)) d0 = f_rows_p<kFPlaneW>(dZ, ((q + 2) & 3) * 32, (q + 2) >> 2, lc);
+                __builtin_amdgcn_sched_barrier(0);
+                if (FULL || ((q + 1) & 3) < HB) gW[0][(q + 1) & 3] = mma32x3(d1, q < 4 ? xb0 : xb1, gW[0][(q + 1) & 3]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (tid == 0) s_tile[it & 3] = tile4;
@@ -1611,10 +1674,21 @@ static int wide_step_impl(const float* obs, const float* actions, const float* r
     const int grid = dual ? pairs : 2 * pairs;
     bool* ad = &attr[dslot][bf3k ? 2 : (dual ? 1 : 0)][num_layers - 1];
     if (bf3k) {
-        switch (num_layers) {
-            case 1: rc = launch_wide(k_mlpw3_step<1>, ad, grid, (size_t)w3::kBytes, s, a); break;
-            case 2: rc = launch_wide(k_mlpw3_step<2>, ad, grid, (size_t)w3::kBytes, s, a); break;
-            default: rc = launch_wide(k_mlpw3_step<3>, ad, grid, (size_t)w3::kBytes, s, a); break;
+        // 128-wide hidden layers over <= 64 / <= 128 state floats: the builds whose matrix chains have compile-time trip counts
+        static bool attr3[kMaxDevices][3][MAXL] = {};
+        // (three layers keep the run-time build: with straight-line chains its 12 x 16 accumulator registers leave the compiler 119
+        // spilled registers and the launch is slower, 739 us against 681; two layers gain, 479 -> 442 us)
+        const int v = (hidden == 128 && num_layers <= 2) ? (D <= 64 ? 1 : 2) : 0;
+        ad = &attr3[dslot][v][num_layers - 1];
+        const size_t lds = (size_t)w3::kBytes;
+        switch (num_layers * 3 + v) {
+            case 3: rc = launch_wide(k_mlpw3_step<1, false, 0>, ad, grid, lds, s, a); break;
+            case 4: rc = launch_wide(k_mlpw3_step<1, true, 4>, ad, grid, lds, s, a); break;
+            case 5: rc = launch_wide(k_mlpw3_step<1, true, 8>, ad, grid, lds, s, a); break;
+            case 6: rc = launch_wide(k_mlpw3_step<2, false, 0>, ad, grid, lds, s, a); break;
+            case 7: rc = launch_wide(k_mlpw3_step<2, true, 4>, ad, grid, lds, s, a); break;
+            case 8: rc = launch_wide(k_mlpw3_step<2, true, 8>, ad, grid, lds, s, a); break;
+            default: rc = launch_wide(k_mlpw3_step<3, false, 0>, ad, grid, lds, s, a); break;
         }
     } else
     switch (num_layers * 2 + (dual ? 1 : 0)) {
