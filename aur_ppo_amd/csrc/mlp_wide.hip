@@ -1036,6 +1036,8 @@ __global__ __launch_bounds__(256, 1) void k_mlpw3_step(const WideArgs a) {
     // in front of those reuses stood the wave through the gathers' HBM latency in the middle of layer 1 (tools/k7w_stamps.py: F1 took
     // 7.5-8.1 k cycles for its 24 matrix instructions).
     auto prefetch = [&](const int* sidx) {
+        int tq = tid;
+        asm volatile("" : "+v"(tq));       // (an opaque copy: what is derived from it is formed here each time, not once and spilled)
         // (the rows' indices are read from LDS first, all of them, and a piece that is not real is pointed at element 0 by 32-bit
         // selects: written as `ok ? row * D + c : 0` the 64-bit product sat in a branch per piece, each behind its own LDS wait --
         // 1.8 k cycles to issue eight requests, tools/k7w_stamps.py)
@@ -1043,10 +1045,10 @@ __global__ __launch_bounds__(256, 1) void k_mlpw3_step(const WideArgs a) {
         if (vec4) {
             int src[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) src[u] = sidx[(tid + u * kThreads) >> 5];
+            for (int u = 0; u < 4; ++u) src[u] = sidx[(tq + u * kThreads) >> 5];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int c4 = (tid & 31) * 4;
+                const int c4 = (tq & 31) * 4;
                 const bool ok = src[u] >= 0 && c4 < D;
                 const unsigned row = ok ? (unsigned)src[u] : 0u, col = ok ? (unsigned)c4 : 0u;
                 dma16(a.obs + ((size_t)row * (unsigned)D + col), sStage + (w * 64 + u * kThreads) * 16);
@@ -1055,7 +1057,7 @@ __global__ __launch_bounds__(256, 1) void k_mlpw3_step(const WideArgs a) {
         } else {
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
-                const int e = tid + u * kThreads, r = e >> 7, c = e & 127;
+                const int e = tq + u * kThreads, r = e >> 7, c = e & 127;
                 const int s1 = sidx[r];
                 const bool ok = s1 >= 0 && c < D;
                 const unsigned row = ok ? (unsigned)s1 : 0u, col = ok ? (unsigned)c : 0u;
@@ -1066,10 +1068,10 @@ __global__ __launch_bounds__(256, 1) void k_mlpw3_step(const WideArgs a) {
         if (net == 0) {
             int sa[2];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) sa[u] = sidx[(tid + u * kThreads) >> 4];
+            for (int u = 0; u < 2; ++u) sa[u] = sidx[(tq + u * kThreads) >> 4];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int c = tid & 15;
+                const int c = tq & 15;
                 const bool ok = sa[u] >= 0 && c < AW;
                 const unsigned row = ok ? (unsigned)sa[u] : 0u, col = ok ? (unsigned)c : 0u;
                 dma4(act_base + ((size_t)row * (unsigned)act_stride + col), sStageA + (w * 64 + u * kThreads) * 4);
@@ -1078,14 +1080,16 @@ __global__ __launch_bounds__(256, 1) void k_mlpw3_step(const WideArgs a) {
         }
         // (every thread, no branch: a conditional load is a write to its destination on the other path, and the wait the compiler
         // puts in front of that write is a wait for every load above it)
-        p_src = sidx[tid & (R - 1)];
+        p_src = sidx[tq & (R - 1)];
         p_rec = a.rec[(size_t)(p_src >= 0 ? p_src : 0) * a.rec_stride];
     };
     // the index row of the tile three ahead, the same way: raw value + whether it is real
     int n_raw = 0;
     bool n_ok = false;
     auto prefetch_idx = [&](int tile) {
-        const int m = tile * R + (tid & (R - 1));
+        int tq = tid;
+        asm volatile("" : "+v"(tq));
+        const int m = tile * R + (tq & (R - 1));
         n_ok = tile < n_tiles && m < a.h.M;
         n_raw = a.idx[n_ok ? m : 0];
     };
@@ -1132,10 +1136,12 @@ __global__ __launch_bounds__(256, 1) void k_mlpw3_step(const WideArgs a) {
         }
         // ---- land the prefetched tile as bf16 planes
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's own pieces have landed in the staging area
+        int tl = tid;
+        asm volatile("" : "+v"(tl));
         if (vec4) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int e = tid + u * kThreads, r = e >> 5, c4 = (e & 31) * 4;
+                const int e = tl + u * kThreads, r = e >> 5, c4 = (e & 31) * 4;
                 const bool ok = (xok >> u) & 1u;
                 const float4 v = *reinterpret_cast<const float4*>(sStage + e * 16);
                 if (c4 < D) store_x4(sX + (c4 >> 6) * kXHalf, r, c4 & 63, ok ? v.x : 0.0f, ok ? v.y : 0.0f, ok ? v.z : 0.0f, ok ? v.w : 0.0f);
@@ -1143,7 +1149,7 @@ __global__ __launch_bounds__(256, 1) void k_mlpw3_step(const WideArgs a) {
         } else {
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
-                const int e = tid + u * kThreads, r = e >> 7, c = e & 127;
+                const int e = tl + u * kThreads, r = e >> 7, c = e & 127;
                 const float v = *reinterpret_cast<const float*>(sStage + e * 4);
                 if (c < D) store_x1(sX + (c >> 6) * kXHalf, r, c & 63, ((xok >> u) & 1u) ? v : 0.0f);
             }
@@ -1151,7 +1157,7 @@ __global__ __launch_bounds__(256, 1) void k_mlpw3_step(const WideArgs a) {
         if (net == 0) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int e = tid + u * kThreads;
+                const int e = tl + u * kThreads;
                 const float v = *reinterpret_cast<const float*>(sStageA + e * 4);
                 sAct[(e >> 4) * LDO + (e & 15)] = ((xok >> (16 + u)) & 1u) ? v : 0.0f;
             }
@@ -1676,8 +1682,9 @@ static int wide_step_impl(const float* obs, const float* actions, const float* r
     if (bf3k) {
         // 128-wide hidden layers over <= 64 / <= 128 state floats: the builds whose matrix chains have compile-time trip counts
         static bool attr3[kMaxDevices][3][MAXL] = {};
-        // (three layers keep the run-time build: with straight-line chains its 12 x 16 accumulator registers leave the compiler 119
-        // spilled registers and the launch is slower, 739 us against 681; two layers gain, 479 -> 442 us)
+        // (three layers keep the run-time build: with straight-line chains its 12 x 16 accumulator registers leave the compiler 53
+        // spilled registers -- freshly loaded weight slices and records among them, each a wait for its load -- and the launch is
+        // slower, 739 us against 681; two layers gain, 479 -> 442 us)
         const int v = (hidden == 128 && num_layers <= 2) ? (D <= 64 ? 1 : 2) : 0;
         ad = &attr3[dslot][v][num_layers - 1];
         const size_t lds = (size_t)w3::kBytes;
