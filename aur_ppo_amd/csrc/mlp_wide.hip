@@ -863,7 +863,9 @@ __device__ unsigned long long g_k7w_stamps[kMaxSlabs][32];
 #endif
 
 // FULL: the hidden layers are 128 wide (four column blocks, eight k-steps) and DK > 0: layer 1 runs DK k-steps (state width <= 16 DK,
-// zero-padded) -- every trip count of the matrix chains is then a compile-time constant.  With run-time counts each k-step sat in
+// zero-padded) -- every trip count of the matrix chains is then a compile-time constant (the phase-level `cb < HB` stays a run-time
+// test even so: as a constant it let the compiler's code motion loose across the phases and cost the three-layer build 51 spilled
+// registers, among them freshly loaded weight slices).  With run-time counts each k-step sat in
 // its own branch, and the wait the compiler places at such a join is lgkmcnt(0): the fragments requested for the NEXT k-step were
 // waited for before the current one's products were issued (75-87 cycles per matrix instruction, tools/k7w_stamps.py).
 template <int NL, bool FULL, int DK>
@@ -1105,7 +1107,7 @@ __global__ __launch_bounds__(256, 1) void k_mlpw3_step(const WideArgs a) {
             s_tile[0] = t0; s_tile[1] = t0 + 1; s_tile[2] = t0 + 2; s_tile[3] = t0 + 3;
         }
     }
-    if (FULL || cb < HB) load_w(0, 0, nksD);                        // layer 1's slice for the first tile
+    if (cb < HB) load_w(0, 0, nksD);                        // layer 1's slice for the first tile
     __syncthreads();
     if (tid < R) {
         sIdx[tid] = load_idx(s_tile[0]);
@@ -1174,7 +1176,7 @@ __global__ __launch_bounds__(256, 1) void k_mlpw3_step(const WideArgs a) {
         for (int l = 0; l < NL; ++l) {
             f32x16 acc = zero16();
             WSUB0();
-            if (FULL || cb < HB) {
+            if (cb < HB) {
                 // (every chain below asks for the fragments of k-step ks + 1 BEFORE it issues the six products of k-step ks: with the
                 // reads and the products of a pair of k-steps in one scheduling region the compiler put the reads first and the wave
                 // waited out their latency in front of every pair -- 75-87 cycles per matrix instruction instead of 32,
@@ -1224,7 +1226,7 @@ __global__ __launch_bounds__(256, 1) void k_mlpw3_step(const WideArgs a) {
                 prefetch_idx(tile3);
             }
             WSUB(25);
-            if (FULL || cb < HB) {
+            if (cb < HB) {
                 // the slice used next: the following layer's forward copy, or (behind the last layer) the top layer's backward copy
                 if (l + 1 < NL) load_w(l + 1, 0, nksH);
                 else if (NL > 1) load_w(NL - 1, 1, nksH);
@@ -1310,7 +1312,7 @@ __global__ __launch_bounds__(256, 1) void k_mlpw3_step(const WideArgs a) {
             for (int r = 0; r < R; ++r) cs += src[r * LDO];
             g_head += cs;
         }
-        if (FULL || cb < HB) {
+        if (cb < HB) {
             char* const HL = sH(NL - 1);
             f32x16 acc = zero16();
             acc = mma32x3(plain_cols(sDo, kDoRowW, kDoPlaneW, 0, 0, ln), plain_cols(sW3, kW3RowW, kW3PlaneW, 0, cb * 32, ln), acc);
@@ -1327,7 +1329,7 @@ __global__ __launch_bounds__(256, 1) void k_mlpw3_step(const WideArgs a) {
         // ---- hidden layers, top down: dW_l, dH_{l-1} -> dZ_{l-1} (in place)
 #pragma unroll
         for (int l = NL - 1; l >= 1; --l) {
-            if (FULL || cb < HB) {
+            if (cb < HB) {
                 const char* const dZ = sH(l);
                 char* const Hp = sH(l - 1);
                 load_w_hi(l, 1, nksH);                      // (behind the dW chains below)
@@ -1682,10 +1684,7 @@ static int wide_step_impl(const float* obs, const float* actions, const float* r
     if (bf3k) {
         // 128-wide hidden layers over <= 64 / <= 128 state floats: the builds whose matrix chains have compile-time trip counts
         static bool attr3[kMaxDevices][3][MAXL] = {};
-        // (three layers keep the run-time build: with straight-line chains its 12 x 16 accumulator registers leave the compiler 53
-        // spilled registers -- freshly loaded weight slices and records among them, each a wait for its load -- and the launch is
-        // slower, 739 us against 681; two layers gain, 479 -> 442 us)
-        const int v = (hidden == 128 && num_layers <= 2) ? (D <= 64 ? 1 : 2) : 0;
+        const int v = hidden == 128 ? (D <= 64 ? 1 : 2) : 0;
         ad = &attr3[dslot][v][num_layers - 1];
         const size_t lds = (size_t)w3::kBytes;
         switch (num_layers * 3 + v) {
@@ -1695,7 +1694,9 @@ static int wide_step_impl(const float* obs, const float* actions, const float* r
             case 6: rc = launch_wide(k_mlpw3_step<2, false, 0>, ad, grid, lds, s, a); break;
             case 7: rc = launch_wide(k_mlpw3_step<2, true, 4>, ad, grid, lds, s, a); break;
             case 8: rc = launch_wide(k_mlpw3_step<2, true, 8>, ad, grid, lds, s, a); break;
-            default: rc = launch_wide(k_mlpw3_step<3, false, 0>, ad, grid, lds, s, a); break;
+            case 9: rc = launch_wide(k_mlpw3_step<3, false, 0>, ad, grid, lds, s, a); break;
+            case 10: rc = launch_wide(k_mlpw3_step<3, true, 4>, ad, grid, lds, s, a); break;
+            default: rc = launch_wide(k_mlpw3_step<3, true, 8>, ad, grid, lds, s, a); break;
         }
     } else
     switch (num_layers * 2 + (dual ? 1 : 0)) {
