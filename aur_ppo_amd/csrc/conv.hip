@@ -562,8 +562,12 @@ __global__ __launch_bounds__(kConvThreads, 2) void k_conv3x3_wgrad(const ConvWgr
             }
         }
     };
-    auto fetch = [&](int c, float (&v)[kSlots][4]) {
+    // (the loads' results are not touched here: the shift of a row-start quad and the zero of a row-end pixel wait in `fl` -- two bits
+    // per row -- until the chunk is split, two chunks later.  Applied at this point, the selects sat right behind the loads and every
+    // request was a wait for its own loads.)
+    auto fetch = [&](int c, float (&v)[kSlots][4], unsigned& fl) {
         const unsigned (*const tab)[32] = s_tab[c % 3];
+        fl = 0u;
 #pragma unroll
         for (int u = 0; u < kSlots; ++u) {
             const u32x4 t = *reinterpret_cast<const u32x4*>(&tab[row_tap[u]][q4]);        // this row's offsets of the quad's pixels
@@ -579,11 +583,10 @@ __global__ __launch_bounds__(kConvThreads, 2) void k_conv3x3_wgrad(const ConvWgr
                     const bool shl = t.x >= kOob;                 // pixel 0 is off the row: the load starts at pixel 1
                     const unsigned off = t.y < kOob ? (shl ? t.y : t.y - 4u) : kOob;
                     L = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, off + row_off[u], 0, 0));
-                    const float l0 = __uint_as_float(L.x), l1 = __uint_as_float(L.y), l2 = __uint_as_float(L.z), l3 = __uint_as_float(L.w);
-                    v[u][0] = shl ? 0.0f : l0;
-                    v[u][1] = shl ? l0 : l1;
-                    v[u][2] = shl ? l1 : l2;
-                    v[u][3] = shl ? l2 : (t.w < kOob ? l3 : 0.0f);
+                    v[u][0] = __uint_as_float(L.x); v[u][1] = __uint_as_float(L.y);
+                    v[u][2] = __uint_as_float(L.z); v[u][3] = __uint_as_float(L.w);
+                    fl |= (shl ? 1u : 0u) << (2 * u);
+                    fl |= (t.w < kOob ? 0u : 2u) << (2 * u);
                 }
             } else {
                 const __amdgpu_buffer_rsrc_t r = u < kSlotsA ? ra : rb;
@@ -605,20 +608,28 @@ __global__ __launch_bounds__(kConvThreads, 2) void k_conv3x3_wgrad(const ConvWgr
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
     const int n_chunks = (n_px + 31) >> 5;
     // one chunk: its values (requested two chunks ago) -> planes -> products; meanwhile chunk c + 2 is requested into the same registers
-    auto step = [&](int c, float (&v)[kSlots][4]) {
+    auto step = [&](int c, float (&v)[kSlots][4], unsigned& fl) {
         __syncthreads();                                    // the previous chunk's fragments have been read; table c + 2 is written
 #pragma unroll
         for (int u = 0; u < kSlots; ++u) {
+            float x0 = v[u][0], x1 = v[u][1], x2 = v[u][2], x3 = v[u][3];
+            if (QUAD && u >= kSlotsA) {
+                const bool shl = (fl >> (2 * u)) & 1u, z3 = (fl >> (2 * u + 1)) & 1u;
+                x3 = shl ? x2 : (z3 ? 0.0f : x3);
+                x2 = shl ? x1 : x2;
+                x1 = shl ? x0 : x1;
+                x0 = shl ? 0.0f : x0;
+            }
             unsigned a0, a1, a2, b0, b1, b2;
-            split3(v[u][0], v[u][1], a0, a1, a2);
-            split3(v[u][2], v[u][3], b0, b1, b2);
+            split3(x0, x1, a0, a1, a2);
+            split3(x2, x3, b0, b1, b2);
             const int o = foff(crow + 32 * u, q4);
             *reinterpret_cast<u32x2*>(s_img + 0 * PL + o) = u32x2{a0, b0};
             *reinterpret_cast<u32x2*>(s_img + 1 * PL + o) = u32x2{a1, b1};
             *reinterpret_cast<u32x2*>(s_img + 2 * PL + o) = u32x2{a2, b2};
         }
         __syncthreads();
-        if (c + 2 < n_chunks) fetch(c + 2, v);
+        if (c + 2 < n_chunks) fetch(c + 2, v, fl);
         if (c + 3 < n_chunks) table(c + 3);                 // (slot c % 3: last read by fetch(c), before this chunk's first barrier)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -631,15 +642,16 @@ __global__ __launch_bounds__(kConvThreads, 2) void k_conv3x3_wgrad(const ConvWgr
         }
     };
     float va[kSlots][4], vb[kSlots][4];
+    unsigned fa = 0u, fb = 0u;
     table(0);
     if (n_chunks > 1) table(1);
     if (n_chunks > 2) table(2);
     __syncthreads();
-    fetch(0, va);
-    if (n_chunks > 1) fetch(1, vb);
+    fetch(0, va, fa);
+    if (n_chunks > 1) fetch(1, vb, fb);
     for (int c = 0; c < n_chunks; c += 2) {
-        step(c, va);
-        if (c + 1 < n_chunks) step(c + 1, vb);
+        step(c, va, fa);
+        if (c + 1 < n_chunks) step(c + 1, vb, fb);
     }
     // C[m = co][n]: the lane holds the filter column, its registers the channels -- rows of `part` are contiguous over the lanes
     float* const out = a.part + (size_t)s * a.Co * a.NK;
