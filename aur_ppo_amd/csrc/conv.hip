@@ -392,7 +392,9 @@ __global__ __launch_bounds__(kConvThreads, 2) void k_linear_wgrad(const WgradArg
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
     float pa[4][4], pb[4][4];
+    unsigned pok = 0u;               // bit u: dY piece u is real; bit 4 + u: X piece u (the zeroing waits until the chunk is staged)
     auto fetch = [&](long long m0) {
+        pok = 0u;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const long long r = m0 + r_of + 8 * u;
@@ -400,8 +402,10 @@ __global__ __launch_bounds__(kConvThreads, 2) void k_linear_wgrad(const WgradArg
             const bool oka = okr && n0 + c4 < a.N, okb = okr && k0 + c4 < a.K;      // (N and K are multiples of 4)
             const float4 va = *reinterpret_cast<const float4*>(a.dy + (oka ? (size_t)r * a.N + n0 + c4 : (size_t)0));
             const float4 vb = *reinterpret_cast<const float4*>(a.x + (okb ? (size_t)r * a.K + k0 + c4 : (size_t)0));
-            pa[u][0] = oka ? va.x : 0.0f; pa[u][1] = oka ? va.y : 0.0f; pa[u][2] = oka ? va.z : 0.0f; pa[u][3] = oka ? va.w : 0.0f;
-            pb[u][0] = okb ? vb.x : 0.0f; pb[u][1] = okb ? vb.y : 0.0f; pb[u][2] = okb ? vb.z : 0.0f; pb[u][3] = okb ? vb.w : 0.0f;
+            pa[u][0] = va.x; pa[u][1] = va.y; pa[u][2] = va.z; pa[u][3] = va.w;
+            pb[u][0] = vb.x; pb[u][1] = vb.y; pb[u][2] = vb.z; pb[u][3] = vb.w;
+            pok |= (oka ? 1u : 0u) << u;
+            pok |= (okb ? 1u : 0u) << (4 + u);
         }
     };
     fetch(m_lo);
@@ -410,8 +414,11 @@ __global__ __launch_bounds__(kConvThreads, 2) void k_linear_wgrad(const WgradArg
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int r = r_of + 8 * u;
-            store_x4(imgA + (c4 >> 6) * 3 * kXPlane, r, c4 & 63, pa[u][0], pa[u][1], pa[u][2], pa[u][3]);
-            store_x4(imgB + (c4 >> 6) * 3 * kXPlane, r, c4 & 63, pb[u][0], pb[u][1], pb[u][2], pb[u][3]);
+            const bool oka = (pok >> u) & 1u, okb = (pok >> (4 + u)) & 1u;
+            store_x4(imgA + (c4 >> 6) * 3 * kXPlane, r, c4 & 63, oka ? pa[u][0] : 0.0f, oka ? pa[u][1] : 0.0f, oka ? pa[u][2] : 0.0f,
+                     oka ? pa[u][3] : 0.0f);
+            store_x4(imgB + (c4 >> 6) * 3 * kXPlane, r, c4 & 63, okb ? pb[u][0] : 0.0f, okb ? pb[u][1] : 0.0f, okb ? pb[u][2] : 0.0f,
+                     okb ? pb[u][3] : 0.0f);
         }
         __syncthreads();
         if (m0 + 32 < m_hi) fetch(m0 + 32);                 // the next chunk's rows, behind this chunk's products
