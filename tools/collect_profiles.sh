@@ -12,6 +12,7 @@
 #   k2_stamps.txt, k2_time.txt          accept-kernel stamps and the shuffle pipeline's stand-alone time for both accept kernels
 #   bench_wide_{3x128,3x64,2x128}*.json/csv   bench.py --hidden-dim/--num-layers (K7w / K8w), plain and under rocprofv3
 #   wide_bench.json                     tools/bench_wide.py: K7w / K8w against the per-op path over the -d / -nl shapes
+#   (PART=4) k7w_stamps_*.txt, k7w_time.txt, conv_bench_*.json, wgrad_bench_*.json, conv_wgrad_k12_mfma_pmc.json, bench_robot{3,5}.json, equiv5_k11_k12.json
 # Each step runs under its own timeout; a step that times out stops the script (no GPU step after a hang).
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/prof_final
@@ -23,7 +24,7 @@ run() {  # run <seconds> <cmd...>
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "step timed out: $*" >&2; exit $rc; fi
   return $rc
 }
-# PART=1 | 2 | 3 runs a third of the list (a gpurun call is capped at 20 minutes); default: everything
+# PART=1 | 2 | 3 | 4 runs a part of the list (a gpurun call is capped at 20 minutes); default: everything
 part() { [ "${PART:-all}" = all ] || [ "$PART" = "$1" ]; }
 export TMPDIR=/tmp
 prof() {  # prof <tag> <bench args...>
@@ -80,6 +81,24 @@ run 900 bash tools/pmc_mfma.sh k7 k_mlp_step3 72351744 bench.py --steps 2 --warm
 cp gpurun_out/k7_mfma_pmc.json $O/mlp3_mfma_pmc.json
 run 900 bash tools/pmc_mfma.sh wide3x128 k_mlpw 0 bench.py --hidden-dim 128 --num-layers 3 --steps 2 --warmup 2 --no-probe --cpu-baseline-updates 0 --no-parity --shard-envs-per-gpu 0 > /dev/null 2>&1
 cp gpurun_out/wide3x128_mfma_pmc.json $O/mlp_wide3_3x128_mfma_pmc.json
+fi
+if part 4; then
+# round 4: the wide fused step's stamps / stand-alone times, the convolution kernels' benches and counters, the robot updates
+cd $R
+for shape in "128 3" "128 2"; do set -- $shape; run 300 python3 $R/tools/k7w_stamps.py $1 $2 > $O/k7w_stamps_$2x$1.txt 2>&1; done
+: > $O/k7w_time.txt
+for sh in 128,3,64 128,3,128 128,2,64 128,2,128 96,2,64 128,1,64; do K7W_SHAPE=$sh run 120 python3 $R/tools/k7w_time.py > $O/.step.txt 2>&1; tail -1 $O/.step.txt >> $O/k7w_time.txt; done
+run 300 python3 $R/tools/bench_conv.py --batch 2048 > $O/conv_bench_b2048.json 2> /dev/null
+run 300 python3 $R/tools/bench_wgrad.py --batch 8192 > $O/wgrad_bench_b8192.json 2> /dev/null
+run 300 python3 $R/tools/bench_wgrad.py --batch 4096 --size 84 > $O/wgrad_bench_b4096_84.json 2> /dev/null
+run 300 python3 $R/tools/bench_wgrad.py --batch 4096 --size 84 --equiv > $O/wgrad_bench_b4096_equiv.json 2> /dev/null
+run 200 python3 $R/tools/bench_wgrad.py --linear > $O/wgrad_bench_linear.json 2> /dev/null
+run 900 bash tools/pmc_mfma.sh k12 k_conv3x3_wgrad 0 tools/bench_wgrad.py --batch 2048 > /dev/null 2>&1
+cp gpurun_out/k12_mfma_pmc.json $O/conv_wgrad_k12_mfma_pmc.json
+run 600 python3 $R/bench.py --workload robot3 --steps 5 --warmup 3 > $O/bench_robot3.json 2> $O/bench_robot3.err
+run 900 python3 $R/bench.py --workload robot5 > $O/bench_robot5.json 2> $O/bench_robot5.err
+run 900 python3 $R/tools/bench_robot.py --config 5 --equivariant --updates 2 --kernel-table > $O/equiv5_k11_k12.json 2> $O/equiv5.err
+rm -f $O/.step.txt
 fi
 cd $R
 ls -la $O
