@@ -343,33 +343,54 @@ __global__ __launch_bounds__(256, DUAL ? 2 : 1) void k_mlpw_step(const WideArgs 
     // staging slots: 8 threads per row, columns (tid & 7) + 8u
     const int x_r = tid >> 3, x_c0 = tid & 7;
     float xr[XS], ar[2];
+    unsigned xok = 0u;               // bit u: xr[u] is real; bit 16 + u: ar[u] (the zeroing waits until the tile lands)
     float4 p_rec = make_float4(0.f, 0.f, 0.f, 0.f);
-    int p_src = -1, n_idx = -1;
+    int p_src = -1, n_raw = 0;
+    bool n_ok = false;
     auto load_idx = [&](int tile) -> int {
         const int m = tile * R + tid;
         return (tile < n_tiles && m < a.h.M) ? a.idx[m] : -1;
     };
     const float* const act_base = a.actions ? a.actions : reinterpret_cast<const float*>(a.rec) + 4;
     const int act_stride = a.actions ? AW : 16;
+    // Every load below is unconditional (a piece that is not real reads element 0) and nothing is computed from its result here:
+    // a conditional load is a write to its destination on the other path, and the wait the compiler puts in front of that write --
+    // or in front of an `ok ? v : 0` select -- is a wait for every load above it (k_mlpw3_step's lesson).
     auto prefetch = [&](const int* sidx) {
-        const int src = sidx[x_r];
+        int tq = tid;
+        asm volatile("" : "+v"(tq));
+        const int src = sidx[tq >> 3];
+        xok = 0u;
 #pragma unroll
         for (int u = 0; u < XS; ++u) {
-            const int c = x_c0 + 8 * u;
-            xr[u] = (src >= 0 && c < D) ? a.obs[(size_t)src * D + c] : 0.0f;
+            const int c = (tq & 7) + 8 * u;
+            const bool ok = src >= 0 && c < D;
+            const unsigned row = ok ? (unsigned)src : 0u, col = ok ? (unsigned)c : 0u;
+            xr[u] = a.obs[(size_t)row * (unsigned)D + col];
+            xok |= ok ? (1u << u) : 0u;
         }
         if (DUAL || net == 0) {
+            int sa[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) sa[u] = sidx[(tq + u * kThreads) >> 4];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int e = tid + u * kThreads, r = e >> 4, c = e & 15;
-                const int sa = sidx[r];
-                ar[u] = (sa >= 0 && c < AW) ? act_base[(size_t)sa * act_stride + c] : 0.0f;
+                const int c = tq & 15;
+                const bool ok = sa[u] >= 0 && c < AW;
+                const unsigned row = ok ? (unsigned)sa[u] : 0u, col = ok ? (unsigned)c : 0u;
+                ar[u] = act_base[(size_t)row * (unsigned)act_stride + col];
+                xok |= ok ? (1u << (16 + u)) : 0u;
             }
         }
-        if (tid < R) {
-            p_src = sidx[tid];
-            if (p_src >= 0) p_rec = a.rec[(size_t)p_src * a.rec_stride];
-        }
+        p_src = sidx[tq & (R - 1)];
+        p_rec = a.rec[(size_t)(p_src >= 0 ? p_src : 0) * a.rec_stride];
+    };
+    auto prefetch_idx = [&](int tile) {
+        int tq = tid;
+        asm volatile("" : "+v"(tq));
+        const int m = tile * R + (tq & (R - 1));
+        n_ok = tile < n_tiles && m < a.h.M;
+        n_raw = a.idx[n_ok ? m : 0];
     };
     // Tiles are handed out by a counter, not strided statically: a workgroup that starts late (its CU held by one of the
     // side stream's shuffle kernels) then simply takes fewer -- with static striding every launch that overlapped them ran
@@ -394,7 +415,7 @@ __global__ __launch_bounds__(256, DUAL ? 2 : 1) void k_mlpw_step(const WideArgs 
     }
     __syncthreads();
     prefetch(s.sIdx);
-    if (tid < R) n_idx = load_idx(s_tile[2]);
+    prefetch_idx(s_tile[2]);
     for (int it = 0;; ++it) {
         const int tile = s_tile[it & 3];
         if (tile >= n_tiles) break;
@@ -405,25 +426,25 @@ __global__ __launch_bounds__(256, DUAL ? 2 : 1) void k_mlpw_step(const WideArgs 
 #pragma unroll
         for (int u = 0; u < XS; ++u) {
             const int c = x_c0 + 8 * u;
-            if (c < D) s.sX[x_r * LD_ + c] = xr[u];
+            if (c < D) s.sX[x_r * LD_ + c] = ((xok >> u) & 1u) ? xr[u] : 0.0f;
         }
         if (DUAL || net == 0) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int e = tid + u * kThreads;
-                s.sAct[(e >> 4) * LDO + (e & 15)] = ar[u];
+                s.sAct[(e >> 4) * LDO + (e & 15)] = ((xok >> (16 + u)) & 1u) ? ar[u] : 0.0f;
             }
         }
         if (tid < R) {
             s.sSrc[tid] = p_src;
             s.sRec[tid] = p_rec;
-            s.sIdx[(it & 1) * R + tid] = n_idx;
+            s.sIdx[(it & 1) * R + tid] = n_ok ? n_raw : -1;
         }
         __syncthreads();
         // the next tile's rows are fetched behind this tile's math -- except with three layers, whose accumulators leave
         // no registers to hold them that long: there they are fetched at the end of the tile (latency exposed, ~5 %)
         if (NL < 3) prefetch(s.sIdx + ((it + 1) & 1) * R);
-        if (tid < R) n_idx = load_idx(tile3);
+        prefetch_idx(tile3);
 
         forward_tile<NL, EARLY, DUAL>(a, s, net, cb, HB, DB, early);
         // the tile after the three already known: asked for here, where this wave has no loads queued behind the atomic
