@@ -38,6 +38,27 @@ def test_argument_validation_without_gpu():
     assert lib.aurppo_mt19937_destroy(None) == 0
 
 
+def test_weight_gradient_workspace_plans_without_gpu():
+    """aurppo_conv3x3_wgrad_ws_bytes / aurppo_linear_wgrad_ws_bytes are host-side plans (tile and slice counts): every hidden layer
+    of both image configs gets a workspace of S x Co x Ci x 9 floats with S the slice count; unsupported shapes say 0."""
+    from aur_ppo_amd import _lib
+    lib = _lib.load()
+    for B, Ci, Co, S, pad in [(8192, 16, 32, 64, 1), (8192, 32, 64, 32, 1), (8192, 64, 128, 16, 1), (8192, 128, 256, 8, 1),
+                              (8192, 256, 256, 8, 0), (4096, 64, 128, 42, 1), (4096, 512, 512, 5, 0), (1, 3, 5, 3, 1)]:
+        nb = lib.aurppo_conv3x3_wgrad_ws_bytes(B, Ci, Co, S, S, pad)
+        per_slice = Co * Ci * 9 * 4
+        assert nb >= per_slice + 64 and (nb - 64) % per_slice == 0, (B, Ci, Co, S, pad, nb)
+        tiles = -(-Co // (128 if Co > 64 else 64)) * -(-(Ci * 9) // (128 if Co > 64 else 256))
+        slices = (nb - 64) // per_slice
+        assert 1 <= slices and slices * tiles <= 4 * 512, (slices, tiles)          # at most four rounds of two workgroups per CU
+    assert lib.aurppo_conv3x3_wgrad_ws_bytes(4, 16, 32, 8, 8, 3) == 0              # padding outside 0..2
+    assert lib.aurppo_conv3x3_wgrad_ws_bytes(4, 16, 32, 2, 2, 0) == 0              # empty output
+    assert lib.aurppo_conv3x3_wgrad_ws_bytes(1, 512, 8, 1024, 1024, 1) == 0        # one image of 2 GB
+    assert lib.aurppo_linear_wgrad_ws_bytes(131072, 256, 256) >= 256 * 256 * 4 + 64
+    assert lib.aurppo_linear_wgrad_ws_bytes(0, 256, 256) == 0
+    assert lib.aurppo_conv3x3_wgrad_f32(None, None, None, 1, 16, 32, 8, 8, 1, None, None) == -1 and b"null pointer" in lib.aurppo_last_error()
+
+
 @pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-only check")
 def test_no_cpu_fallback_exists():
     from aur_ppo_amd import hip_ops as H
