@@ -883,13 +883,13 @@ __device__ unsigned long long g_k7w_stamps[kMaxSlabs][32];
 #define WSUB0() do { } while (0)
 #endif
 
-// FULL: the hidden layers are 128 wide (four column blocks, eight k-steps) and DK > 0: layer 1 runs DK k-steps (state width <= 16 DK,
-// zero-padded) -- every trip count of the matrix chains is then a compile-time constant (the phase-level `cb < HB` stays a run-time
+// HK > 0: the hidden layers run HK k-steps of 16 (8: 113..128 units, 6: 81..96; zero-padded) and DK > 0: layer 1 runs DK k-steps
+// (state width <= 16 DK, zero-padded) -- every trip count of the matrix chains is then a compile-time constant (the phase-level `cb < HB` stays a run-time
 // test even so: as a constant it let the compiler's code motion loose across the phases and cost the three-layer build 51 spilled
 // registers, among them freshly loaded weight slices).  With run-time counts each k-step sat in
 // its own branch, and the wait the compiler places at such a join is lgkmcnt(0): the fragments requested for the NEXT k-step were
 // waited for before the current one's products were issued (75-87 cycles per matrix instruction, tools/k7w_stamps.py).
-template <int NL, bool FULL, int DK>
+template <int NL, int HK, int DK>
 __global__ __launch_bounds__(256, 1) void k_mlpw3_step(const WideArgs a) {
     using namespace w3;
 #ifdef K7W_STAMPS
@@ -907,7 +907,9 @@ __global__ __launch_bounds__(256, 1) void k_mlpw3_step(const WideArgs a) {
     const int net = (int)(blockIdx.x & 1), cb = w, pair = (int)(blockIdx.x >> 1);
     const int D = a.D, A = a.A, Hd = a.Hd;
     const int HB = (Hd + 31) >> 5, DB = (D + 31) >> 5;
-    const int nksD = DK > 0 ? DK : (D + 15) >> 4, nksH = FULL ? 8 : (Hd + 15) >> 4, nks2H = FULL ? 4 : (Hd + 31) >> 5;
+    constexpr bool FULL = HK > 0;
+    constexpr int HBK = (HK + 1) / 2;         // column blocks of 32 (compile-time builds)
+    const int nksD = DK > 0 ? DK : (D + 15) >> 4, nksH = FULL ? HK : (Hd + 15) >> 4, nks2H = FULL ? HBK : (Hd + 31) >> 5;
     const int AW = a.continuous ? A : 1;
     const int out_dim = net == 0 ? A : 1;
 
@@ -1223,13 +1225,13 @@ __global__ __launch_bounds__(256, 1) void k_mlpw3_step(const WideArgs a) {
                     Frag3 f0 = f_cols_p<kFPlaneW>(sH(l - 1), 0, lc), f1 = f0;
 #pragma unroll
                     for (int ks = 0; ks < kWopKs; ks += 2) {
-                        if (FULL ? ks + 1 < 8 : ks + 1 < nksH) f1 = f_cols_p<kFPlaneW>(sH(l - 1), ks + 1, lc);
+                        if (FULL ? ks + 1 < HK : ks + 1 < nksH) f1 = f_cols_p<kFPlaneW>(sH(l - 1), ks + 1, lc);
                         __builtin_amdgcn_sched_barrier(0);
-                        if (FULL ? ks < 8 : ks < nksH) acc = mma32x3(f0, wfrag(ks), acc);
+                        if (FULL ? ks < HK : ks < nksH) acc = mma32x3(f0, wfrag(ks), acc);
                         __builtin_amdgcn_sched_barrier(0);
-                        if (FULL ? ks + 2 < 8 : ks + 2 < nksH) f0 = f_cols_p<kFPlaneW>(sH(l - 1), ks + 2, lc);
+                        if (FULL ? ks + 2 < HK : ks + 2 < nksH) f0 = f_cols_p<kFPlaneW>(sH(l - 1), ks + 2, lc);
                         __builtin_amdgcn_sched_barrier(0);
-                        if (FULL ? ks + 1 < 8 : ks + 1 < nksH) acc = mma32x3(f1, wfrag(ks + 1), acc);
+                        if (FULL ? ks + 1 < HK : ks + 1 < nksH) acc = mma32x3(f1, wfrag(ks + 1), acc);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -1361,14 +1363,14 @@ __global__ __launch_bounds__(256, 1) void k_mlpw3_step(const WideArgs a) {
                     Frag3 d0 = f_rows_p<kFPlaneW>(dZ, 0, 0, lc), d1 = d0;
 #pragma unroll
                     for (int q = 0; q < 8; q += 2) {            // q = 4 ks + ob
-                        if (FULL || ((q + 1) & 3) < HB) d1 = f_rows_p<kFPlaneW>(dZ, ((q + 1) & 3) * 32, (q + 1) >> 2, lc);
+                        if (FULL ? ((q + 1) & 3) < HBK : ((q + 1) & 3) < HB) d1 = f_rows_p<kFPlaneW>(dZ, ((q + 1) & 3) * 32, (q + 1) >> 2, lc);
                         if (q == 2) hb1 = f_rows_p<kFPlaneW>(Hp, cb * 32, 1, lc);
                         __builtin_amdgcn_sched_barrier(0);
-                        if (FULL || (q & 3) < HB) gW[l][q & 3] = mma32x3(d0, q < 4 ? hb0 : hb1, gW[l][q & 3]);
+                        if (FULL ? (q & 3) < HBK : (q & 3) < HB) gW[l][q & 3] = mma32x3(d0, q < 4 ? hb0 : hb1, gW[l][q & 3]);
                         __builtin_amdgcn_sched_barrier(0);
-                        if (q + 2 < 8 && (FULL || ((q + 2) & 3) < HB)) d0 = f_rows_p<kFPlaneW>(dZ, ((q + 2) & 3) * 32, (q + 2) >> 2, lc);
+                        if (q + 2 < 8 && (FULL ? ((q + 2) & 3) < HBK : ((q + 2) & 3) < HB)) d0 = f_rows_p<kFPlaneW>(dZ, ((q + 2) & 3) * 32, (q + 2) >> 2, lc);
                         __builtin_amdgcn_sched_barrier(0);
-                        if (FULL || ((q + 1) & 3) < HB) gW[l][(q + 1) & 3] = mma32x3(d1, q < 4 ? hb0 : hb1, gW[l][(q + 1) & 3]);
+                        if (FULL ? ((q + 1) & 3) < HBK : ((q + 1) & 3) < HB) gW[l][(q + 1) & 3] = mma32x3(d1, q < 4 ? hb0 : hb1, gW[l][(q + 1) & 3]);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -1377,13 +1379,13 @@ __global__ __launch_bounds__(256, 1) void k_mlpw3_step(const WideArgs a) {
                     Frag3 f0 = f_cols_p<kFPlaneW>(dZ, 0, lc), f1 = f0;
 #pragma unroll
                     for (int ks = 0; ks < kWopKs; ks += 2) {
-                        if (FULL ? ks + 1 < 8 : ks + 1 < nksH) f1 = f_cols_p<kFPlaneW>(dZ, ks + 1, lc);
+                        if (FULL ? ks + 1 < HK : ks + 1 < nksH) f1 = f_cols_p<kFPlaneW>(dZ, ks + 1, lc);
                         __builtin_amdgcn_sched_barrier(0);
-                        if (FULL ? ks < 8 : ks < nksH) acc = mma32x3(f0, wfrag(ks), acc);
+                        if (FULL ? ks < HK : ks < nksH) acc = mma32x3(f0, wfrag(ks), acc);
                         __builtin_amdgcn_sched_barrier(0);
-                        if (FULL ? ks + 2 < 8 : ks + 2 < nksH) f0 = f_cols_p<kFPlaneW>(dZ, ks + 2, lc);
+                        if (FULL ? ks + 2 < HK : ks + 2 < nksH) f0 = f_cols_p<kFPlaneW>(dZ, ks + 2, lc);
                         __builtin_amdgcn_sched_barrier(0);
-                        if (FULL ? ks + 1 < 8 : ks + 1 < nksH) acc = mma32x3(f1, wfrag(ks + 1), acc);
+                        if (FULL ? ks + 1 < HK : ks + 1 < nksH) acc = mma32x3(f1, wfrag(ks + 1), acc);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -1404,14 +1406,14 @@ __global__ __launch_bounds__(256, 1) void k_mlpw3_step(const WideArgs a) {
             Frag3 d0 = f_rows_p<kFPlaneW>(dZ, 0, 0, lc), d1 = d0;
 #pragma unroll
             for (int q = 0; q < 8; q += 2) {
-                if (FULL || ((q + 1) & 3) < HB) d1 = f_rows_p<kFPlaneW>(dZ, ((q + 1) & 3) * 32, (q + 1) >> 2, lc);
+                if (FULL ? ((q + 1) & 3) < HBK : ((q + 1) & 3) < HB) d1 = f_rows_p<kFPlaneW>(dZ, ((q + 1) & 3) * 32, (q + 1) >> 2, lc);
                 if (q == 2) xb1 = x_cols(sX + (cb >> 1) * kXHalf, 1, (cb & 1) * 32, lc);
                 __builtin_amdgcn_sched_barrier(0);
-                if (FULL || (q & 3) < HB) gW[0][q & 3] = mma32x3(d0, q < 4 ? xb0 : xb1, gW[0][q & 3]);
+                if (FULL ? (q & 3) < HBK : (q & 3) < HB) gW[0][q & 3] = mma32x3(d0, q < 4 ? xb0 : xb1, gW[0][q & 3]);
                 __builtin_amdgcn_sched_barrier(0);
-                if (q + 2 < 8 && (FULL || ((q + 2) & 3) < HB)) d0 = f_rows_p<kFPlaneW>(dZ, ((q + 2) & 3) * 32, (q + 2) >> 2, lc);
+                if (q + 2 < 8 && (FULL ? ((q + 2) & 3) < HBK : ((q + 2) & 3) < HB)) d0 = f_rows_p<kFPlaneW>(dZ, ((q + 2) & 3) * 32, (q + 2) >> 2, lc);
                 __builtin_amdgcn_sched_barrier(0);
-                if (FULL || ((q + 1) & 3) < HB) gW[0][(q + 1) & 3] = mma32x3(d1, q < 4 ? xb0 : xb1, gW[0][(q + 1) & 3]);
+                if (FULL ? ((q + 1) & 3) < HBK : ((q + 1) & 3) < HB) gW[0][(q + 1) & 3] = mma32x3(d1, q < 4 ? xb0 : xb1, gW[0][(q + 1) & 3]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -1703,22 +1705,25 @@ static int wide_step_impl(const float* obs, const float* actions, const float* r
     const int grid = dual ? pairs : 2 * pairs;
     bool* ad = &attr[dslot][bf3k ? 2 : (dual ? 1 : 0)][num_layers - 1];
     if (bf3k) {
-        // 128-wide hidden layers over <= 64 / <= 128 state floats: the builds whose matrix chains have compile-time trip counts
-        static bool attr3[kMaxDevices][3][MAXL] = {};
-        const int v = hidden == 128 ? (D <= 64 ? 1 : 2) : 0;
+        // hidden layers of 113..128 / 81..96 units over <= 64 / <= 128 state floats: the builds whose matrix chains have compile-time
+        // trip counts (v = 1..4); every other width runs the build with run-time counts (v = 0)
+        static bool attr3[kMaxDevices][5][MAXL] = {};
+        const int hk = hidden > 112 ? 8 : ((hidden > 80 && hidden <= 96) ? 6 : 0);
+        const int v = hk == 0 ? 0 : (hk == 8 ? 1 : 3) + (D <= 64 ? 0 : 1);
         ad = &attr3[dslot][v][num_layers - 1];
         const size_t lds = (size_t)w3::kBytes;
-        switch (num_layers * 3 + v) {
-            case 3: rc = launch_wide(k_mlpw3_step<1, false, 0>, ad, grid, lds, s, a); break;
-            case 4: rc = launch_wide(k_mlpw3_step<1, true, 4>, ad, grid, lds, s, a); break;
-            case 5: rc = launch_wide(k_mlpw3_step<1, true, 8>, ad, grid, lds, s, a); break;
-            case 6: rc = launch_wide(k_mlpw3_step<2, false, 0>, ad, grid, lds, s, a); break;
-            case 7: rc = launch_wide(k_mlpw3_step<2, true, 4>, ad, grid, lds, s, a); break;
-            case 8: rc = launch_wide(k_mlpw3_step<2, true, 8>, ad, grid, lds, s, a); break;
-            case 9: rc = launch_wide(k_mlpw3_step<3, false, 0>, ad, grid, lds, s, a); break;
-            case 10: rc = launch_wide(k_mlpw3_step<3, true, 4>, ad, grid, lds, s, a); break;
-            default: rc = launch_wide(k_mlpw3_step<3, true, 8>, ad, grid, lds, s, a); break;
+#define AURPPO_W3_LAUNCH(NLV)                                                                                   \
+        switch (v) {                                                                                            \
+            case 1: rc = launch_wide(k_mlpw3_step<NLV, 8, 4>, ad, grid, lds, s, a); break;                        \
+            case 2: rc = launch_wide(k_mlpw3_step<NLV, 8, 8>, ad, grid, lds, s, a); break;                        \
+            case 3: rc = launch_wide(k_mlpw3_step<NLV, 6, 4>, ad, grid, lds, s, a); break;                        \
+            case 4: rc = launch_wide(k_mlpw3_step<NLV, 6, 8>, ad, grid, lds, s, a); break;                        \
+            default: rc = launch_wide(k_mlpw3_step<NLV, 0, 0>, ad, grid, lds, s, a); break;                       \
         }
+        if (num_layers == 1) { AURPPO_W3_LAUNCH(1) }
+        else if (num_layers == 2) { AURPPO_W3_LAUNCH(2) }
+        else { AURPPO_W3_LAUNCH(3) }
+#undef AURPPO_W3_LAUNCH
     } else
     switch (num_layers * 2 + (dual ? 1 : 0)) {
         case 2: rc = launch_wide(k_mlpw_step<1, false>, ad, grid, wide_lds_bytes<false, 1>(1), s, a); break;
