@@ -96,8 +96,13 @@ __device__ __forceinline__ TrLane tr_lane16(int lane) {      // 16x16x32 operand
 
 // ---- fragments.  `img` = plane 0 of the image (bytes), planes follow at `plane` bytes.
 // A[m = s][k = d] (32x32x16) from an X image, k-step ks: row read
+// (Every fragment address below is written as  <k-step 0's address of this lane>  +/^  <a constant of the k-step>: the swizzles are
+// XORs of a few address bits, so a k-step moves the address by a constant -- xoff(s, d ^ c) = xoff(s, d) ^ (c << 1) for c a multiple
+// of 8, foff(f + 16 k, s) = foff(f, s) + 1024 k, foff(f, s ^ 16) = foff(f, s) ^ 32 -- and written this way the lane-dependent part
+// is formed once per chain and the k-step's part is an immediate or one XOR, where the plain form cost ~8 vector instructions per
+// k-step to re-derive (~500 of k_mlpw3_step's 3 040 per tile).)
 __device__ __forceinline__ Frag3 x_rows(const char* img, int ks, int lane) {
-    const int o = xoff(lane & 31, 16 * ks + 8 * (lane >> 5));
+    const int o = xoff(lane & 31, 8 * (lane >> 5)) ^ (ks << 5);              // = xoff(lane & 31, 16 ks + 8 (lane >> 5)), ks < 4
     Frag3 f;
 #pragma unroll
     for (int p = 0; p < 3; ++p) f.p[p] = lds_b128(img + p * kXPlane + o);
@@ -106,16 +111,17 @@ __device__ __forceinline__ Frag3 x_rows(const char* img, int ks, int lane) {
 // B[k = s][n = d0 + 0..31] (32x32x16) from an X image, k-step ks (16 samples): transposed read
 __device__ __forceinline__ Frag3 x_cols(const char* img, int ks, int d0, int lane) {
     const TrLane t = tr_lane32(lane);
-    const int s = 16 * ks + t.kq, d = d0 + t.m0;
-    const int o0 = xoff(s, d), o1 = xoff(s + 4, d);
+    const int d = d0 + t.m0;
+    // xoff(16 ks + q, d) = 16 ks * kXRow + (xoff(q, d) ^ ((ks & 1) << 5)): xswz(16 ks + q) = xswz(q) ^ (2 (ks & 1)) for q < 16
+    const int o0 = (xoff(t.kq, d) ^ ((ks & 1) << 5)) + 16 * ks * kXRow, o1 = (xoff(t.kq + 4, d) ^ ((ks & 1) << 5)) + 16 * ks * kXRow;
     Frag3 f;
 #pragma unroll
     for (int p = 0; p < 3; ++p) f.p[p] = join_tr(lds_tr(img + p * kXPlane + o0), lds_tr(img + p * kXPlane + o1));
     return f;
 }
 // A[m = f0 + 0..31][k = s] or B[k = s][n = f0 + 0..31] (32x32x16) from an F image, k-step ks (16 samples): row read
-__device__ __forceinline__ Frag3 f_rows(const char* img, int f0, int ks, int lane) {
-    const int o = foff(f0 + (lane & 31), 16 * ks + 8 * (lane >> 5));
+__device__ __forceinline__ Frag3 f_rows(const char* img, int f0, int ks, int lane) {       // f0 a multiple of 16, ks < 2
+    const int o = (foff(lane & 31, 8 * (lane >> 5)) ^ (ks << 5)) + f0 * kFRow;      // = foff(f0 + (lane & 31), 16 ks + 8 (lane >> 5))
     Frag3 f;
 #pragma unroll
     for (int p = 0; p < 3; ++p) f.p[p] = lds_b128(img + p * kFPlane + o);
@@ -124,8 +130,7 @@ __device__ __forceinline__ Frag3 f_rows(const char* img, int f0, int ks, int lan
 // A[m = s][k = f] (32x32x16) from an F image, k-step ks (16 features): transposed read
 __device__ __forceinline__ Frag3 f_cols(const char* img, int ks, int lane) {
     const TrLane t = tr_lane32(lane);
-    const int f = 16 * ks + t.kq;
-    const int o0 = foff(f, t.m0), o1 = foff(f + 4, t.m0);
+    const int o0 = foff(t.kq, t.m0) + 16 * ks * kFRow, o1 = foff(t.kq + 4, t.m0) + 16 * ks * kFRow;      // = foff(16 ks + kq (+ 4), m0): kq + 4 < 16
     Frag3 r;
 #pragma unroll
     for (int p = 0; p < 3; ++p) r.p[p] = join_tr(lds_tr(img + p * kFPlane + o0), lds_tr(img + p * kFPlane + o1));
@@ -134,8 +139,7 @@ __device__ __forceinline__ Frag3 f_cols(const char* img, int ks, int lane) {
 // 16x16x32: A[m = s0 + 0..15][k = f] from an F image, k-step ks (32 features): transposed read
 __device__ __forceinline__ Frag3 f_cols16(const char* img, int s0, int ks, int lane) {
     const TrLane t = tr_lane16(lane);
-    const int f = 32 * ks + t.kq;
-    const int o0 = foff(f, s0 + t.m0), o1 = foff(f + 4, s0 + t.m0);
+    const int o0 = foff(t.kq, s0 + t.m0) + 32 * ks * kFRow, o1 = foff(t.kq + 4, s0 + t.m0) + 32 * ks * kFRow;      // kq + 4 < 32
     Frag3 r;
 #pragma unroll
     for (int p = 0; p < 3; ++p) r.p[p] = join_tr(lds_tr(img + p * kFPlane + o0), lds_tr(img + p * kFPlane + o1));

@@ -479,7 +479,7 @@ constexpr unsigned kOob = 0x80000000u;      // buffer offsets from here on read 
 
 template <int PL>
 __device__ __forceinline__ Frag3 wg_rows(const char* img, int f0, int ks, int lane) {       // A[m = f0 + ..][k] / B[k][n = f0 + ..]
-    const int o = foff(f0 + (lane & 31), 16 * ks + 8 * (lane >> 5));
+    const int o = (foff(lane & 31, 8 * (lane >> 5)) ^ (ks << 5)) + f0 * kFRow;      // (f0 a multiple of 16: lane part + constants, bf16x3.h)
     Frag3 f;
 #pragma unroll
     for (int p = 0; p < 3; ++p) f.p[p] = lds_b128(img + p * PL + o);

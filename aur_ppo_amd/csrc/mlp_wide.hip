@@ -707,8 +707,8 @@ static_assert(oH % 16 == 0 && oW3 % 16 == 0 && oDo % 16 == 0 && oOut % 16 == 0 &
 static_assert(kBytes <= 160 * 1024, "one workgroup per CU");
 
 template <int PL>
-__device__ __forceinline__ Frag3 f_rows_p(const char* img, int f0, int ks, int lane) {
-    const int o = foff(f0 + (lane & 31), 16 * ks + 8 * (lane >> 5));
+__device__ __forceinline__ Frag3 f_rows_p(const char* img, int f0, int ks, int lane) {      // (addresses as in bf16x3.h: lane part + k-step constant)
+    const int o = (foff(lane & 31, 8 * (lane >> 5)) ^ (ks << 5)) + f0 * kFRow;
     Frag3 f;
 #pragma unroll
     for (int p = 0; p < 3; ++p) f.p[p] = lds_b128(img + p * PL + o);
@@ -717,8 +717,7 @@ __device__ __forceinline__ Frag3 f_rows_p(const char* img, int f0, int ks, int l
 template <int PL>
 __device__ __forceinline__ Frag3 f_cols_p(const char* img, int ks, int lane) {
     const TrLane t = tr_lane32(lane);
-    const int f = 16 * ks + t.kq;
-    const int o0 = foff(f, t.m0), o1 = foff(f + 4, t.m0);
+    const int o0 = foff(t.kq, t.m0) + 16 * ks * kFRow, o1 = foff(t.kq + 4, t.m0) + 16 * ks * kFRow;
     Frag3 r;
 #pragma unroll
     for (int p = 0; p < 3; ++p) r.p[p] = join_tr(lds_tr(img + p * PL + o0), lds_tr(img + p * PL + o1));
@@ -727,8 +726,7 @@ __device__ __forceinline__ Frag3 f_cols_p(const char* img, int ks, int lane) {
 template <int PL>
 __device__ __forceinline__ Frag3 f_cols16_p(const char* img, int s0, int ks, int lane) {
     const TrLane t = tr_lane16(lane);
-    const int f = 32 * ks + t.kq;
-    const int o0 = foff(f, s0 + t.m0), o1 = foff(f + 4, s0 + t.m0);
+    const int o0 = foff(t.kq, s0 + t.m0) + 32 * ks * kFRow, o1 = foff(t.kq + 4, s0 + t.m0) + 32 * ks * kFRow;
     Frag3 r;
 #pragma unroll
     for (int p = 0; p < 3; ++p) r.p[p] = join_tr(lds_tr(img + p * PL + o0), lds_tr(img + p * PL + o1));
