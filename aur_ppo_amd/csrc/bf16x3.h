@@ -204,7 +204,7 @@ __device__ __forceinline__ void store_acc_f(char* img, int f0, const float (&v)[
         unsigned a0, a1, a2, b0, b1, b2;
         split3(v[4 * gq + 0], v[4 * gq + 1], a0, a1, a2);
         split3(v[4 * gq + 2], v[4 * gq + 3], b0, b1, b2);
-        const int o = foff(f, 8 * gq + 4 * h);
+        const int o = foff(f, 4 * h) ^ (gq << 4);       // = foff(f, 8 gq + 4 h)
         *reinterpret_cast<u32x2*>(img + 0 * kFPlane + o) = u32x2{a0, b0};
         *reinterpret_cast<u32x2*>(img + 1 * kFPlane + o) = u32x2{a1, b1};
         *reinterpret_cast<u32x2*>(img + 2 * kFPlane + o) = u32x2{a2, b2};
@@ -215,7 +215,7 @@ __device__ __forceinline__ void load_acc_f(const char* img, int f0, float (&v)[1
     const int f = f0 + (lane & 31), h = lane >> 5;
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
-        const int o = foff(f, 8 * gq + 4 * h);
+        const int o = foff(f, 4 * h) ^ (gq << 4);       // = foff(f, 8 gq + 4 h)
         const u32x2 q0 = *reinterpret_cast<const u32x2*>(img + 0 * kFPlane + o);
         const u32x2 q1 = *reinterpret_cast<const u32x2*>(img + 1 * kFPlane + o);
         const u32x2 q2 = *reinterpret_cast<const u32x2*>(img + 2 * kFPlane + o);

@@ -630,7 +630,7 @@ __global__ __launch_bounds__(kConvThreads, 2) void k_conv3x3_wgrad(const ConvWgr
             unsigned a0, a1, a2, b0, b1, b2;
             split3(x0, x1, a0, a1, a2);
             split3(x2, x3, b0, b1, b2);
-            const int o = foff(crow + 32 * u, q4);
+            const int o = foff(crow, q4) + 32 * u * kFRow;      // = foff(crow + 32 u, q4)
             *reinterpret_cast<u32x2*>(s_img + 0 * PL + o) = u32x2{a0, b0};
             *reinterpret_cast<u32x2*>(s_img + 1 * PL + o) = u32x2{a1, b1};
             *reinterpret_cast<u32x2*>(s_img + 2 * PL + o) = u32x2{a2, b2};

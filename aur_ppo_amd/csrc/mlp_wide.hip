@@ -769,7 +769,7 @@ __device__ __forceinline__ void tanh_store_p(char* img, int f0, const f32x16& ac
         unsigned a0, a1, a2, b0, b1, b2;
         split3(tanh_fast(acc[4 * gq + 0] + bias), tanh_fast(acc[4 * gq + 1] + bias), a0, a1, a2);
         split3(tanh_fast(acc[4 * gq + 2] + bias), tanh_fast(acc[4 * gq + 3] + bias), b0, b1, b2);
-        const int o = foff(f, 8 * gq + 4 * h);
+        const int o = foff(f, 4 * h) ^ (gq << 4);       // = foff(f, 8 gq + 4 h)
         *reinterpret_cast<u32x2*>(img + 0 * PL + o) = u32x2{a0, b0};
         *reinterpret_cast<u32x2*>(img + 1 * PL + o) = u32x2{a1, b1};
         *reinterpret_cast<u32x2*>(img + 2 * PL + o) = u32x2{a2, b2};
@@ -783,7 +783,7 @@ __device__ __forceinline__ float dz_in_place_p(char* img, int f0, const f32x16& 
     u32x2 q[4][3];
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
-        const int o = foff(f, 8 * gq + 4 * h);
+        const int o = foff(f, 4 * h) ^ (gq << 4);       // = foff(f, 8 gq + 4 h)
 #pragma unroll
         for (int p = 0; p < 3; ++p) q[gq][p] = *reinterpret_cast<const u32x2*>(img + p * PL + o);
     }
@@ -797,7 +797,7 @@ __device__ __forceinline__ float dz_in_place_p(char* img, int f0, const f32x16& 
         unsigned a0, a1, a2, b0, b1, b2;
         split3(d0, d1, a0, a1, a2);
         split3(d2, d3, b0, b1, b2);
-        const int o = foff(f, 8 * gq + 4 * h);
+        const int o = foff(f, 4 * h) ^ (gq << 4);       // = foff(f, 8 gq + 4 h)
         *reinterpret_cast<u32x2*>(img + 0 * PL + o) = u32x2{a0, b0};
         *reinterpret_cast<u32x2*>(img + 1 * PL + o) = u32x2{a1, b1};
         *reinterpret_cast<u32x2*>(img + 2 * PL + o) = u32x2{a2, b2};
