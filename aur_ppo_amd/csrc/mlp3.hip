@@ -88,48 +88,45 @@ static_assert(kGbOff + 4 * 4 * 2 * 32 <= kDynBytes, "hand-over scratch must fit 
 
 // Epilogues, four values (one 8-byte store per plane) at a time so that nothing but the accumulator is live across them.
 // tanh(acc + bias) of a 32x32 block into an F image:
-__device__ __forceinline__ void tanh_store(char* img, int f0, const f32x16& acc, float bias, int lane) {
+// om[e] = 1 - tanh^2 of the same element, kept in registers for the backward pass (dz_from_regs): re-read from the image's planes it
+// cost three unpacks and two adds per value to join and twelve LDS reads per block (the register file has had room for the 2 x 16
+// values since the fragment addresses stopped being re-derived, bf16x3.h)
+__device__ __forceinline__ void tanh_store(char* img, int f0, const f32x16& acc, float bias, int lane, float (&om)[16]) {
     const int f = f0 + (lane & 31), h = lane >> 5;
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
         unsigned a0, a1, a2, b0, b1, b2;
-        split3(tanh_fast(acc[4 * gq + 0] + bias), tanh_fast(acc[4 * gq + 1] + bias), a0, a1, a2);
-        split3(tanh_fast(acc[4 * gq + 2] + bias), tanh_fast(acc[4 * gq + 3] + bias), b0, b1, b2);
+        const float t0 = tanh_fast(acc[4 * gq + 0] + bias), t1 = tanh_fast(acc[4 * gq + 1] + bias);
+        const float t2 = tanh_fast(acc[4 * gq + 2] + bias), t3 = tanh_fast(acc[4 * gq + 3] + bias);
+        om[4 * gq + 0] = 1.0f - t0 * t0; om[4 * gq + 1] = 1.0f - t1 * t1;
+        om[4 * gq + 2] = 1.0f - t2 * t2; om[4 * gq + 3] = 1.0f - t3 * t3;
+        split3(t0, t1, a0, a1, a2);
+        split3(t2, t3, b0, b1, b2);
         const int o = foff(f, 4 * h) ^ (gq << 4);       // = foff(f, 8 gq + 4 h)
         *reinterpret_cast<u32x2*>(img + 0 * kFPlane + o) = u32x2{a0, b0};
         *reinterpret_cast<u32x2*>(img + 1 * kFPlane + o) = u32x2{a1, b1};
         *reinterpret_cast<u32x2*>(img + 2 * kFPlane + o) = u32x2{a2, b2};
     }
 }
-// dZ = dH * (1 - h^2) over the block of h that sits in the image, written back in its place; returns the lane's column sum
-__device__ __forceinline__ float dz_in_place(char* img, int f0, const f32x16& dh, int lane) {
+// dZ = dH * (1 - h^2), (1 - h^2) from the forward pass's registers, written over the block of h in the image; returns the lane's column sum
+__device__ __forceinline__ float dz_from_regs(char* img, int f0, const f32x16& dh, const float (&om)[16], int lane) {
     const int f = f0 + (lane & 31), h = lane >> 5;
     float colsum = 0.0f;
-    u32x2 q[4][3];
-#pragma unroll
-    for (int gq = 0; gq < 4; ++gq) {      // all twelve reads go out together
-        const int o = foff(f, 4 * h) ^ (gq << 4);       // = foff(f, 8 gq + 4 h)
-#pragma unroll
-        for (int p = 0; p < 3; ++p) q[gq][p] = *reinterpret_cast<const u32x2*>(img + p * kFPlane + o);
-    }
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
-        const float h0 = join_lo(q[gq][0].x, q[gq][1].x, q[gq][2].x), h1 = join_hi(q[gq][0].x, q[gq][1].x, q[gq][2].x);
-        const float h2 = join_lo(q[gq][0].y, q[gq][1].y, q[gq][2].y), h3 = join_hi(q[gq][0].y, q[gq][1].y, q[gq][2].y);
-        const float d0 = dh[4 * gq + 0] * (1.0f - h0 * h0), d1 = dh[4 * gq + 1] * (1.0f - h1 * h1);
-        const float d2 = dh[4 * gq + 2] * (1.0f - h2 * h2), d3 = dh[4 * gq + 3] * (1.0f - h3 * h3);
+        const float d0 = dh[4 * gq + 0] * om[4 * gq + 0], d1 = dh[4 * gq + 1] * om[4 * gq + 1];
+        const float d2 = dh[4 * gq + 2] * om[4 * gq + 2], d3 = dh[4 * gq + 3] * om[4 * gq + 3];
         colsum += (d0 + d1) + (d2 + d3);
         unsigned a0, a1, a2, b0, b1, b2;
         split3(d0, d1, a0, a1, a2);
         split3(d2, d3, b0, b1, b2);
-        const int o = foff(f, 4 * h) ^ (gq << 4);       // = foff(f, 8 gq + 4 h)
+        const int o = foff(f, 4 * h) ^ (gq << 4);
         *reinterpret_cast<u32x2*>(img + 0 * kFPlane + o) = u32x2{a0, b0};
         *reinterpret_cast<u32x2*>(img + 1 * kFPlane + o) = u32x2{a1, b1};
         *reinterpret_cast<u32x2*>(img + 2 * kFPlane + o) = u32x2{a2, b2};
     }
     return colsum;
 }
-
 __device__ __forceinline__ void lds_add(double* p, double v) {
     (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -431,6 +428,7 @@ __global__ __launch_bounds__(kThreads3, 1) void k_mlp_step3(const MlpArgs a) {
     const unsigned long long clk0 = st_last, rt0 = wall_clock64();
 #endif
 
+    float om1[16], om2[16];                     // 1 - H1^2, 1 - H2^2 of this wave's blocks, from the forward to the backward phases
     for (int it = 0; s_first[set] != 0; ++it) {
         int ln = lane, sl = st;
         asm volatile("" : "+v"(ln), "+v"(sl));    // opaque per-tile copies: LDS addresses are re-derived inside the phases
@@ -478,7 +476,7 @@ __global__ __launch_bounds__(kThreads3, 1) void k_mlp_step3(const MlpArgs a) {
             XSTAMP(0);
             load_w(1);                                   // W2 (forward) arrives behind the epilogue and the barrier
             XSTAMP(1);
-            tanh_store(sH1, cb * 32, acc, sB1[net * H + cb * 32 + (ln & 31)], ln);
+            tanh_store(sH1, cb * 32, acc, sB1[net * H + cb * 32 + (ln & 31)], ln, om1);
         }
         STAMP3(1);
         pair_bar();
@@ -487,7 +485,7 @@ __global__ __launch_bounds__(kThreads3, 1) void k_mlp_step3(const MlpArgs a) {
             f32x16 acc = zero16();
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) acc = mma32x3(f_cols(sH1, ks, ln), wfrag(ks), acc);
-            tanh_store(sH2, cb * 32, acc, sB2[net * H + cb * 32 + (ln & 31)], ln);
+            tanh_store(sH2, cb * 32, acc, sB2[net * H + cb * 32 + (ln & 31)], ln, om2);
         }
         STAMP3(2);
         pair_bar();
@@ -581,7 +579,7 @@ __global__ __launch_bounds__(kThreads3, 1) void k_mlp_step3(const MlpArgs a) {
 #pragma unroll
                 for (int q = 0; q < 2; ++q) gW3[q] = mma16x3(da, f_rows16(sH2, cb * 32 + 16 * q, ln), gW3[q]);
             }
-            float colsum = dz_in_place(sH2, cb * 32, acc, ln);
+            float colsum = dz_from_regs(sH2, cb * 32, acc, om2, ln);
             colsum += __shfl_xor(colsum, 32, kWave);
             gb2 += colsum;
         }
@@ -599,7 +597,7 @@ __global__ __launch_bounds__(kThreads3, 1) void k_mlp_step3(const MlpArgs a) {
             f32x16 acc = zero16();
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) acc = mma32x3(f_cols(sH2, ks, ln), wfrag(ks), acc);
-            float colsum = dz_in_place(sH1, cb * 32, acc, ln);
+            float colsum = dz_from_regs(sH1, cb * 32, acc, om1, ln);
             colsum += __shfl_xor(colsum, 32, kWave);
             gb1 += colsum;
         }
