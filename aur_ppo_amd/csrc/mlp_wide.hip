@@ -761,38 +761,35 @@ __device__ __forceinline__ float row16_max(float v) {
     return v;
 }
 // tanh(acc + bias) of a 32x32 block into an F image, four values (one 8-byte store per plane) at a time
+// (om[e] = 1 - tanh^2 of the same element stays in registers for the backward pass, as in k_mlp_step3: joined again from the image's
+// planes it cost three unpacks and two adds per value and twelve LDS reads per block)
 template <int PL>
-__device__ __forceinline__ void tanh_store_p(char* img, int f0, const f32x16& acc, float bias, int lane) {
+__device__ __forceinline__ void tanh_store_p(char* img, int f0, const f32x16& acc, float bias, int lane, float (&om)[16]) {
     const int f = f0 + (lane & 31), h = lane >> 5;
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
         unsigned a0, a1, a2, b0, b1, b2;
-        split3(tanh_fast(acc[4 * gq + 0] + bias), tanh_fast(acc[4 * gq + 1] + bias), a0, a1, a2);
-        split3(tanh_fast(acc[4 * gq + 2] + bias), tanh_fast(acc[4 * gq + 3] + bias), b0, b1, b2);
+        const float t0 = tanh_fast(acc[4 * gq + 0] + bias), t1 = tanh_fast(acc[4 * gq + 1] + bias);
+        const float t2 = tanh_fast(acc[4 * gq + 2] + bias), t3 = tanh_fast(acc[4 * gq + 3] + bias);
+        om[4 * gq + 0] = 1.0f - t0 * t0; om[4 * gq + 1] = 1.0f - t1 * t1;
+        om[4 * gq + 2] = 1.0f - t2 * t2; om[4 * gq + 3] = 1.0f - t3 * t3;
+        split3(t0, t1, a0, a1, a2);
+        split3(t2, t3, b0, b1, b2);
         const int o = foff(f, 4 * h) ^ (gq << 4);       // = foff(f, 8 gq + 4 h)
         *reinterpret_cast<u32x2*>(img + 0 * PL + o) = u32x2{a0, b0};
         *reinterpret_cast<u32x2*>(img + 1 * PL + o) = u32x2{a1, b1};
         *reinterpret_cast<u32x2*>(img + 2 * PL + o) = u32x2{a2, b2};
     }
 }
-// dZ = dH * (1 - h^2) over the block of h that sits in the image, written back in its place; returns the lane's column sum
+// dZ = dH * (1 - h^2), (1 - h^2) from the forward pass's registers, written over the block of h in the image; returns the lane's column sum
 template <int PL>
-__device__ __forceinline__ float dz_in_place_p(char* img, int f0, const f32x16& dh, int lane) {
+__device__ __forceinline__ float dz_from_regs_p(char* img, int f0, const f32x16& dh, const float (&om)[16], int lane) {
     const int f = f0 + (lane & 31), h = lane >> 5;
     float colsum = 0.0f;
-    u32x2 q[4][3];
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
-        const int o = foff(f, 4 * h) ^ (gq << 4);       // = foff(f, 8 gq + 4 h)
-#pragma unroll
-        for (int p = 0; p < 3; ++p) q[gq][p] = *reinterpret_cast<const u32x2*>(img + p * PL + o);
-    }
-#pragma unroll
-    for (int gq = 0; gq < 4; ++gq) {
-        const float h0 = join_lo(q[gq][0].x, q[gq][1].x, q[gq][2].x), h1 = join_hi(q[gq][0].x, q[gq][1].x, q[gq][2].x);
-        const float h2 = join_lo(q[gq][0].y, q[gq][1].y, q[gq][2].y), h3 = join_hi(q[gq][0].y, q[gq][1].y, q[gq][2].y);
-        const float d0 = dh[4 * gq + 0] * (1.0f - h0 * h0), d1 = dh[4 * gq + 1] * (1.0f - h1 * h1);
-        const float d2 = dh[4 * gq + 2] * (1.0f - h2 * h2), d3 = dh[4 * gq + 3] * (1.0f - h3 * h3);
+        const float d0 = dh[4 * gq + 0] * om[4 * gq + 0], d1 = dh[4 * gq + 1] * om[4 * gq + 1];
+        const float d2 = dh[4 * gq + 2] * om[4 * gq + 2], d3 = dh[4 * gq + 3] * om[4 * gq + 3];
         colsum += (d0 + d1) + (d2 + d3);
         unsigned a0, a1, a2, b0, b1, b2;
         split3(d0, d1, a0, a1, a2);
@@ -1142,6 +1139,7 @@ __global__ __launch_bounds__(256, 1) void k_mlpw3_step(const WideArgs a) {
     wt0 = __builtin_readcyclecounter();
     wst[20] = wt0 - wt_entry;            // prologue
 #endif
+    float om[NL][16];                 // 1 - H_l^2 of this wave's blocks, from the forward to the backward phases
     for (int it = 0;; ++it) {
         const int tile = s_tile[it & 3];
         if (tile >= n_tiles) break;
@@ -1251,7 +1249,7 @@ __global__ __launch_bounds__(256, 1) void k_mlpw3_step(const WideArgs a) {
                 // the slice used next: the following layer's forward copy, or (behind the last layer) the top layer's backward copy
                 if (l + 1 < NL) load_w(l + 1, 0, nksH);
                 else if (NL > 1) load_w(NL - 1, 1, nksH);
-                tanh_store_p<kFPlaneW>(sH(l), cb * 32, acc, sB[l * HPW + cb * 32 + (ln & 31)], ln);
+                tanh_store_p<kFPlaneW>(sH(l), cb * 32, acc, sB[l * HPW + cb * 32 + (ln & 31)], ln, om[l]);
             }
             WSUB(l == 0 ? 26 : 29);
             WBAR(1 + l);
@@ -1342,7 +1340,7 @@ __global__ __launch_bounds__(256, 1) void k_mlpw3_step(const WideArgs a) {
 #pragma unroll
                 for (int q = 0; q < 2; ++q) gW3[q] = mma16x3(da, f_rows16_p<kFPlaneW>(HL, cb * 32 + 16 * q, ln), gW3[q]);
             }
-            float colsum = dz_in_place_p<kFPlaneW>(HL, cb * 32, acc, ln);
+            float colsum = dz_from_regs_p<kFPlaneW>(HL, cb * 32, acc, om[NL - 1], ln);
             colsum += __shfl_xor(colsum, 32, kWave);
             gb[NL - 1] += colsum;
         }
@@ -1389,7 +1387,7 @@ __global__ __launch_bounds__(256, 1) void k_mlpw3_step(const WideArgs a) {
                 }
                 if (l - 1 >= 1) load_w(l - 1, 1, nksH);
                 else load_w(0, 0, nksD);                    // layer 1's forward slice for the next tile
-                float colsum = dz_in_place_p<kFPlaneW>(Hp, cb * 32, acc, ln);
+                float colsum = dz_from_regs_p<kFPlaneW>(Hp, cb * 32, acc, om[l - 1], ln);
                 colsum += __shfl_xor(colsum, 32, kWave);
                 gb[l - 1] += colsum;
             }
