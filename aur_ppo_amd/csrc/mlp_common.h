@@ -140,6 +140,14 @@ __device__ __forceinline__ float tanh_fast(float x) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
 
+// tanh(acc + bias) with the bias folded into the exponent's multiply: e^{2 (acc + bias)} = 2^{acc * c + bias * c}, c = 2 log2(e) -- one
+// fused multiply-add in front of v_exp instead of an add and a multiply (bc = bias * kTanhC, formed once per block)
+constexpr float kTanhC = 2.8853900817779268f;
+__device__ __forceinline__ float tanh_fast_fma(float acc, float bc) {
+    const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(acc, kTanhC, bc));
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+
 // All-reduce over aligned groups of 8 lanes with DPP moves (no LDS traffic): lane i <- i ^ 7 (row_half_mirror),
 // then i ^ 1 and i ^ 2 (quad_perm) -- together every lane has combined all 8.
 template <int CTRL>

@@ -766,11 +766,12 @@ __device__ __forceinline__ float row16_max(float v) {
 template <int PL>
 __device__ __forceinline__ void tanh_store_p(char* img, int f0, const f32x16& acc, float bias, int lane, float (&om)[16]) {
     const int f = f0 + (lane & 31), h = lane >> 5;
+    const float bc = bias * kTanhC;
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
         unsigned a0, a1, a2, b0, b1, b2;
-        const float t0 = tanh_fast(acc[4 * gq + 0] + bias), t1 = tanh_fast(acc[4 * gq + 1] + bias);
-        const float t2 = tanh_fast(acc[4 * gq + 2] + bias), t3 = tanh_fast(acc[4 * gq + 3] + bias);
+        const float t0 = tanh_fast_fma(acc[4 * gq + 0], bc), t1 = tanh_fast_fma(acc[4 * gq + 1], bc);
+        const float t2 = tanh_fast_fma(acc[4 * gq + 2], bc), t3 = tanh_fast_fma(acc[4 * gq + 3], bc);
         om[4 * gq + 0] = 1.0f - t0 * t0; om[4 * gq + 1] = 1.0f - t1 * t1;
         om[4 * gq + 2] = 1.0f - t2 * t2; om[4 * gq + 3] = 1.0f - t3 * t3;
         split3(t0, t1, a0, a1, a2);
